@@ -1,0 +1,96 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) FaceNet hot path.
+// Wave = 64 lanes everywhere; nothing here is portable to other targets on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fn {
+
+// ---- status / error plumbing (C ABI returns int, fn_last_error() gives text) ----
+enum { FN_OK = 0, FN_EINVAL = -1, FN_ELAUNCH = -2, FN_EUNSUPPORTED = -3 };
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define FN_REQUIRE(cond, ...)                  \
+    do {                                       \
+        if (!(cond)) {                         \
+            fn::set_error(__VA_ARGS__);        \
+            return fn::FN_EINVAL;              \
+        }                                      \
+    } while (0)
+
+// ---- low-precision storage types: bf16 (training) and f16 (embedding path) ----
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+enum { DT_BF16 = 0, DT_F16 = 1 };
+
+template <typename T> struct LP;  // low-precision traits
+template <> struct LP<__bf16> {
+    typedef bf16x8 vec8;
+    typedef bf16x4 vec4;
+    static __device__ __forceinline__ float to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+    static __device__ __forceinline__ unsigned short from_f32(float f) {
+        __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+        return __builtin_bit_cast(unsigned short, h);
+    }
+    static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct LP<_Float16> {
+    typedef f16x8 vec8;
+    typedef f16x4 vec4;
+    static __device__ __forceinline__ float to_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+    static __device__ __forceinline__ unsigned short from_f32(float f) {
+        _Float16 h = (_Float16)f;
+        return __builtin_bit_cast(unsigned short, h);
+    }
+    static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+// 8 packed 16-bit values <-> 8 floats
+template <typename T> __device__ __forceinline__ void unpack8(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = LP<T>::to_f32((unsigned short)(v[i] & 0xffffu));
+        f[2 * i + 1] = LP<T>::to_f32((unsigned short)(v[i] >> 16));
+    }
+}
+template <typename T> __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        v[i] = (unsigned)LP<T>::from_f32(f[2 * i]) | ((unsigned)LP<T>::from_f32(f[2 * i + 1]) << 16);
+    return v;
+}
+
+// q = m / d, r = m % d for 0 <= m < 2^24 with inv = 1.0f/d (host checks the range).
+__device__ __forceinline__ void fast_divmod(int m, int d, float inv, int& q, int& r) {
+    q = (int)((float)m * inv);
+    r = m - q * d;
+    if (r < 0) { r += d; --q; }
+    else if (r >= d) { r -= d; ++q; }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace fn

@@ -1,0 +1,599 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): forward, data-gradient and weight-gradient.
+//
+// Replaces tf.keras.layers.Conv2D / Dense and the ops Keras wraps around them in
+// facenet/models/inception_resnet_v1.py (Conv2D :90-138,:160-193,:215-248,:269-299,:316-367,
+// :387-430; tf.concat :141,196,251,304,372; residual scale-add :145-148,199-202,254-257; Dense :462)
+// and apps/train_softmax.py:57-63.
+//
+// Design (MI355X-first, not a cuDNN-style translation):
+//   * no im2col buffer: the A operand is gathered straight from the NHWC activation tensor, 16 B
+//     (8 channels) per lane, k = (tap, channel) decoded through a small LDS table;
+//   * 64-lane waves, v_mfma_f32_16x16x32_{bf16,f16}, fp32 accumulate; 4 waves per workgroup;
+//   * tiles staged global -> VGPR -> LDS (issue-early / write-late, double-buffered LDS, one barrier
+//     per 64-deep K step); LDS rows are 128 B with an XOR-8 chunk swizzle so every ds_read_b128
+//     fragment read is bank-conflict free;
+//   * dgrad is the SAME kernel with a transposed-conv gather (so/sk/div parameters) reading the
+//     [Cin][tap][Cout] weight pack;
+//   * wgrad reduces over pixels (K = N*OH*OW): both operands are k-strided in memory, so fragments
+//     come from LDS through ds_read_b64_tr_b16 (hardware transpose read); split-K over pixels with
+//     fp32 global atomics into dW;
+//   * epilogue through LDS (fp32 C tile) so global stores are full 16-B coalesced rows; fused there:
+//     bias, residual scale-add, ReLU, accumulate, BatchNorm batch statistics (sum / sum of squares),
+//     and channel-slice output (ld_out) which makes tf.concat free.
+#include "common.h"
+#include "../../include/facenet_hip.h"
+
+namespace fn {
+
+struct ConvArgs {
+    const unsigned short* src;  // gathered activation operand
+    const unsigned short* wp;   // packed weights [NOUT][KTOT]
+    void* out;
+    const float* bias;
+    float* stats;
+    const unsigned short* resid;
+    int M, PH, PW;   // output pixels = N*PH*PW
+    int SH, SW;      // source spatial dims
+    int CS;          // source channels per tap
+    int NOUT, KTOT, KH, KW;
+    int so, sk, offy, offx, dshift;  // t = p*so + k*sk + off ; src = t >> dshift, valid iff t>=0, (t & ((1<<dshift)-1))==0, src < S
+    int ld_src, ld_out, ld_res;
+    int relu, accumulate, out_f32;
+    float scale;
+    int tiles_m, tiles_n;
+    int stats_sq_off;
+};
+
+// Bijective XCD-aware remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
+// contiguous run of tiles so neighbouring tiles (same A rows / same weights) hit one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+__device__ __forceinline__ int ktab_entry(int kgroup, int KTOT, int CS, int KW) {
+    const int k = kgroup * 8;
+    if (k >= KTOT) return -1;
+    const int tap = k / CS, c = k - tap * CS;
+    const int ky = tap / KW, kx = tap - ky * KW;
+    return (ky << 24) | (kx << 16) | c;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int BK = 64;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MREP = TM / 16, NREP = TN / 16;
+    constexpr int AP = BM / 32, BP = BN / 32;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int STAGE_BYTES = 2 * (A_BYTES + B_BYTES);
+    constexpr int CLD = BN + 4;
+    constexpr int C_BYTES = BM * CLD * 4;
+    constexpr int MAIN_BYTES = STAGE_BYTES > C_BYTES ? STAGE_BYTES : C_BYTES;
+    typedef typename LP<T>::vec8 vec8;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + 2 * A_BYTES;
+    float* sC = reinterpret_cast<float*>(smem);
+    float* sRed = reinterpret_cast<float*>(smem + MAIN_BYTES);         // [2*BN]
+    int* sK = reinterpret_cast<int*>(smem + MAIN_BYTES + 2 * BN * 4);  // [ceil(KTOT/64)*8]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile = xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n);
+    const int tm = tile / a.tiles_n, tn = tile - tm * a.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int ntiles_k = (a.KTOT + BK - 1) / BK;
+
+    for (int i = tid; i < ntiles_k * 8; i += 256) sK[i] = ktab_entry(i, a.KTOT, a.CS, a.KW);
+    if (tid < 2 * BN) sRed[tid] = 0.f;
+
+    // per-thread gather rows
+    const int kg = tid & 7, r0 = tid >> 3;
+    int rowy[AP], rowx[AP], rowbase[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        if (m < a.M) {
+            const int n = m / (a.PH * a.PW), rem = m - n * a.PH * a.PW;
+            const int py = rem / a.PW, px = rem - py * a.PW;
+            rowy[i] = py * a.so + a.offy;
+            rowx[i] = px * a.so + a.offx;
+            rowbase[i] = n * a.SH * a.SW;
+        } else {
+            rowy[i] = -(1 << 28);  // never valid
+            rowx[i] = 0;
+            rowbase[i] = 0;
+        }
+    }
+    const int dmask = (1 << a.dshift) - 1;
+    __syncthreads();
+
+    u32x4 ra[AP], rb[BP];
+    auto load_tile = [&](int kt) {
+        const int e = sK[kt * 8 + kg];
+        const int ky = (e >> 24) & 0xff, kx = (e >> 16) & 0xff, c = e & 0xffff;
+        const int dy = ky * a.sk, dx = kx * a.sk;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int ty = rowy[i] + dy, tx = rowx[i] + dx;
+            const int sy = ty >> a.dshift, sx = tx >> a.dshift;
+            const bool ok = (e >= 0) && (ty >= 0) && (tx >= 0) && (((ty | tx) & dmask) == 0) && (sy < a.SH) && (sx < a.SW);
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) {
+                const long off = (long)(rowbase[i] + sy * a.SW + sx) * a.ld_src + c;
+                v = *reinterpret_cast<const u32x4*>(a.src + off);
+            }
+            ra[i] = v;
+        }
+        const int k = kt * BK + kg * 8;
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            const int co = n0 + r0 + 32 * j;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (co < a.NOUT && k < a.KTOT) v = *reinterpret_cast<const u32x4*>(a.wp + (long)co * a.KTOT + k);
+            rb[j] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int r = r0 + 32 * i;
+            *reinterpret_cast<u32x4*>(sA + buf * A_BYTES + r * 128 + ((kg ^ (r & 7)) << 4)) = ra[i];
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            const int r = r0 + 32 * j;
+            *reinterpret_cast<u32x4*>(sB + buf * B_BYTES + r * 128 + ((kg ^ (r & 7)) << 4)) = rb[j];
+        }
+    };
+
+    f32x4 acc[MREP][NREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < ntiles_k; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ntiles_k) load_tile(kt + 1);  // issue early: latency hides under the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            vec8 fa[MREP], fb[NREP];
+            const int chunk = ks * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < MREP; ++i) {
+                const int r = wm * TM + i * 16 + fr;
+                fa[i] = *reinterpret_cast<const vec8*>(sA + buf * A_BYTES + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) {
+                const int r = wn * TN + j * 16 + fr;
+                fb[j] = *reinterpret_cast<const vec8*>(sB + buf * B_BYTES + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) acc[i][j] = LP<T>::mfma(fa[i], fb[j], acc[i][j]);
+        }
+        if (kt + 1 < ntiles_k) store_tile(buf ^ 1);  // write late: other buffer, last read one barrier ago
+        __syncthreads();
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------
+    if (a.stats) {  // BatchNorm batch statistics from the fp32 accumulators (rows >= M are exact zeros)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[i][j][r];
+                    s += v;
+                    q += v * v;
+                }
+            s += __shfl_xor(s, 16);
+            q += __shfl_xor(q, 16);
+            s += __shfl_xor(s, 32);
+            q += __shfl_xor(q, 32);
+            if (lane < 16) {
+                atomicAdd(&sRed[wn * TN + j * 16 + lane], s);
+                atomicAdd(&sRed[BN + wn * TN + j * 16 + lane], q);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                sC[(wm * TM + i * 16 + fq * 4 + r) * CLD + wn * TN + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+
+    constexpr int CG = BN / 8, RP = 256 / CG;
+    const int cg = tid % CG, rr = tid / CG;
+    const int col = n0 + cg * 8;
+    if (col < a.NOUT) {
+        float bias[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias[e] = (a.bias && col + e < a.NOUT) ? a.bias[col + e] : 0.f;
+        const bool full = (col + 8 <= a.NOUT);
+#pragma unroll
+        for (int ps = 0; ps < BM / RP; ++ps) {
+            const int row = ps * RP + rr;
+            const int m = m0 + row;
+            if (m >= a.M) continue;
+            float v[8];
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(&sC[row * CLD + cg * 8]);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(&sC[row * CLD + cg * 8 + 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = c0[e] + bias[e];
+                v[4 + e] = c1[e] + bias[4 + e];
+            }
+            if (a.resid) {
+                float rv[8];
+                unpack8<T>(*reinterpret_cast<const u32x4*>(a.resid + (long)m * a.ld_res + col), rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = rv[e] + a.scale * v[e];
+            }
+            const long o = (long)m * a.ld_out + col;
+            if (a.out_f32) {
+                float* op = reinterpret_cast<float*>(a.out) + o;
+                if (full && !a.accumulate) {
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
+                    for (int e = 0; e < 8 && col + e < a.NOUT; ++e) {
+                        float x = v[e] + (a.accumulate ? op[e] : 0.f);
+                        op[e] = a.relu ? fmaxf(x, 0.f) : x;
+                    }
+                }
+            } else {
+                unsigned short* op = reinterpret_cast<unsigned short*>(a.out) + o;
+                if (full) {
+                    if (a.accumulate) {
+                        float pv[8];
+                        unpack8<T>(*reinterpret_cast<const u32x4*>(op), pv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += pv[e];
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    *reinterpret_cast<u32x4*>(op) = pack8<T>(v);
+                } else {
+                    for (int e = 0; e < 8 && col + e < a.NOUT; ++e) {
+                        float x = v[e] + (a.accumulate ? LP<T>::to_f32(op[e]) : 0.f);
+                        op[e] = LP<T>::from_f32(a.relu ? fmaxf(x, 0.f) : x);
+                    }
+                }
+            }
+        }
+    }
+    if (a.stats && tid < BN && n0 + tid < a.NOUT) {
+        atomicAdd(&a.stats[n0 + tid], sRed[tid]);
+        atomicAdd(&a.stats[a.stats_sq_off + n0 + tid], sRed[BN + tid]);
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_conv(const ConvArgs& a0, hipStream_t st) {
+    ConvArgs a = a0;
+    a.tiles_m = cdiv(a.M, BM);
+    a.tiles_n = cdiv(a.NOUT, BN);
+    constexpr int STAGE = 2 * (BM * 128 + BN * 128);
+    constexpr int CB = BM * (BN + 4) * 4;
+    const int ntk = cdiv(a.KTOT, 64);
+    const size_t smem = (STAGE > CB ? STAGE : CB) + 2 * BN * 4 + (size_t)ntk * 8 * 4;
+    if (smem > 160 * 1024) {
+        set_error("conv: K=%d needs %zu B of LDS (>160 KiB)", a.KTOT, smem);
+        return FN_EUNSUPPORTED;
+    }
+    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), smem, st, a);
+    return check_launch("conv_igemm");
+}
+
+template <typename T> static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
+    // BN: smallest padded width, ties -> larger tile.
+    int bn = 128;
+    long best = (long)cdiv(a.NOUT, 128) * 128;
+    for (int c : {64, 32}) {
+        const long w = (long)cdiv(a.NOUT, c) * c;
+        if (w < best) { best = w; bn = c; }
+    }
+    // BM=64 when a 128-row tiling cannot even give one block per CU.
+    const bool small = (long)cdiv(a.M, 128) * cdiv(a.NOUT, bn) < 256;
+    if (!small) {
+        if (bn == 128) return launch_conv<T, 128, 128, 2, 2>(a, st);
+        if (bn == 64) return launch_conv<T, 128, 64, 2, 2>(a, st);
+        return launch_conv<T, 128, 32, 4, 1>(a, st);
+    }
+    if (bn == 128) return launch_conv<T, 64, 128, 1, 4>(a, st);
+    if (bn == 64) return launch_conv<T, 64, 64, 2, 2>(a, st);
+    return launch_conv<T, 64, 32, 2, 2>(a, st);
+}
+
+static int check_desc(const fn_conv_desc* d) {
+    FN_REQUIRE(d != nullptr, "conv: null descriptor");
+    FN_REQUIRE(d->dtype == FN_BF16 || d->dtype == FN_F16, "conv: dtype %d unsupported", d->dtype);
+    FN_REQUIRE(d->Cin % 8 == 0, "conv: Cin=%d must be a multiple of 8 (pad the input channels)", d->Cin);
+    FN_REQUIRE(d->ld_x % 8 == 0 && d->ld_x >= d->Cin, "conv: ld_x=%d invalid for Cin=%d", d->ld_x, d->Cin);
+    FN_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride %d unsupported", d->stride);
+    FN_REQUIRE(d->KH >= 1 && d->KW >= 1 && d->KH < 256 && d->KW < 256, "conv: kernel %dx%d unsupported", d->KH, d->KW);
+    FN_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->OH > 0 && d->OW > 0 && d->Cout > 0, "conv: empty geometry");
+    FN_REQUIRE((d->H + 2 * d->pad_h - d->KH) / d->stride + 1 == d->OH && (d->W + 2 * d->pad_w - d->KW) / d->stride + 1 == d->OW,
+               "conv: OHxOW=%dx%d inconsistent with HxW=%dx%d k=%dx%d s=%d pad=%d,%d", d->OH, d->OW, d->H, d->W, d->KH, d->KW,
+               d->stride, d->pad_h, d->pad_w);
+    FN_REQUIRE((long)d->N * d->H * d->W < (1L << 31) / 8 && (long)d->N * d->OH * d->OW < (1L << 24) * 8L,
+               "conv: tensor too large for 32-bit pixel indexing");
+    return FN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: dW[co][kcol] += sum_m dY[m][co] * X[m @ tap(kcol)][ci(kcol)]
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const unsigned short* x;
+    const unsigned short* dy;
+    float* dw;
+    int M, OH, OW, H, W, Cin, Cout, KTOT, KW;
+    int stride, pad_h, pad_w;
+    int ld_x, ld_y;
+    int chunk;  // pixels per split (multiple of 64)
+    int plain;  // 1x1 stride-1: source pixel == output pixel
+    float inv_ow, inv_ohw;
+};
+
+// k-step pixel permutation shared by both operands: tile row of MFMA k index (g = lane>>4, h = half, q)
+//   rho = q + 4*(g&1) + 8*h + 16*(g>>1)   -> the 8 rows a 32-lane half reads per ds_read_b64_tr_b16
+//   are distinct mod 8, which with row strides of 160 B / 288 B makes the transposed reads conflict free.
+template <typename T, int BMW, int BNW>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int BK = 64;                   // pixels per stage
+    constexpr int RSA = BMW * 2 + 32;        // LDS row strides in bytes (160 for 64, 288 for 128, 96 for 32)
+    constexpr int RSB = BNW * 2 + 32;
+    constexpr int A_BYTES = BK * RSA, B_BYTES = BK * RSB;
+    constexpr int CGA = BMW / 8, CGB = BNW / 8;  // 16-B chunks per row
+    constexpr int AP = BK * CGA / 256, BP = BK * CGB / 256;
+    constexpr int WMW = (BMW >= 64) ? 2 : 1, WNW = 4 / WMW;
+    constexpr int TM = BMW / WMW, TN = BNW / WNW;
+    constexpr int MREP = TM / 16, NREP = TN / 16;
+    static_assert(AP >= 1 && BP >= 1 && MREP >= 1 && NREP >= 1, "tile too small");
+    typedef typename LP<T>::vec8 vec8;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;                 // [2][BK][RSA]  dY tile  (rows = pixels, cols = co)
+    unsigned char* sB = smem + 2 * A_BYTES;   // [2][BK][RSB]  X  tile  (rows = pixels, cols = kcol)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WNW, wn = wave % WNW;
+    const int n0 = blockIdx.x * BNW;  // kcol tile
+    const int c0 = blockIdx.y * BMW;  // cout tile
+    const int mbeg = blockIdx.z * a.chunk;
+    const int mend = min(a.M, mbeg + a.chunk);
+    const int nst = (mend - mbeg + BK - 1) / BK;
+    if (nst <= 0) return;
+
+    // B-operand columns handled by this thread (fixed for the whole kernel)
+    int bcol_c[BP], bcol_dy[BP], bcol_dx[BP], brow[BP];
+    bool bcol_ok[BP];
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+        const int cidx = tid + 256 * j;
+        brow[j] = cidx / CGB;
+        const int e = ktab_entry((n0 >> 3) + (cidx % CGB), a.KTOT, a.Cin, a.KW);
+        bcol_ok[j] = e >= 0;
+        bcol_dy[j] = ((e >> 24) & 0xff) - a.pad_h;
+        bcol_dx[j] = ((e >> 16) & 0xff) - a.pad_w;
+        bcol_c[j] = e & 0xffff;
+    }
+    int arow[AP], acol[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int cidx = tid + 256 * i;
+        arow[i] = cidx / CGA;
+        acol[i] = c0 + (cidx % CGA) * 8;
+    }
+
+    u32x4 ra[AP], rb[BP];
+    auto load_tile = [&](int stg) {
+        const int mb = mbeg + stg * BK;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int m = mb + arow[i];
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (m < mend && acol[i] < a.Cout) v = *reinterpret_cast<const u32x4*>(a.dy + (long)m * a.ld_y + acol[i]);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            const int m = mb + brow[j];
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (m < mend && bcol_ok[j]) {
+                long pix;
+                bool ok = true;
+                if (a.plain) {
+                    pix = m;
+                } else {
+                    int n, rem, oy, ox;
+                    fast_divmod(m, a.OH * a.OW, a.inv_ohw, n, rem);
+                    fast_divmod(rem, a.OW, a.inv_ow, oy, ox);
+                    const int iy = oy * a.stride + bcol_dy[j], ix = ox * a.stride + bcol_dx[j];
+                    ok = (iy >= 0) && (ix >= 0) && (iy < a.H) && (ix < a.W);
+                    pix = (long)(n * a.H + iy) * a.W + ix;
+                }
+                if (ok) v = *reinterpret_cast<const u32x4*>(a.x + pix * a.ld_x + bcol_c[j]);
+            }
+            rb[j] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int cidx = tid + 256 * i;
+            *reinterpret_cast<u32x4*>(sA + buf * A_BYTES + arow[i] * RSA + (cidx % CGA) * 16) = ra[i];
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            const int cidx = tid + 256 * j;
+            *reinterpret_cast<u32x4*>(sB + buf * B_BYTES + brow[j] * RSB + (cidx % CGB) * 16) = rb[j];
+        }
+    };
+
+    f32x4 acc[MREP][NREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    // transposed-read addressing: lane -> (g, q, p); supplies the address of row rho(g,h,q), columns 4p..4p+3
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+    const int rho0 = q + 4 * (g & 1) + 16 * (g >> 1);  // + 8*h + 32*ks
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+
+    for (int stg = 0; stg < nst; ++stg) {
+        const int buf = stg & 1;
+        if (stg + 1 < nst) load_tile(stg + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            vec8 fa[MREP], fb[NREP];
+#pragma unroll
+            for (int i = 0; i < MREP; ++i) {
+                const unsigned char* base = sA + buf * A_BYTES + (wm * TM + i * 16 + 4 * p) * 2;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + (rho0 + 32 * ks) * RSA));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + (rho0 + 8 + 32 * ks) * RSA));
+                fa[i] = __builtin_bit_cast(vec8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) {
+                const unsigned char* base = sB + buf * B_BYTES + (wn * TN + j * 16 + 4 * p) * 2;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + (rho0 + 32 * ks) * RSB));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + (rho0 + 8 + 32 * ks) * RSB));
+                fb[j] = __builtin_bit_cast(vec8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) acc[i][j] = LP<T>::mfma(fa[i], fb[j], acc[i][j]);
+        }
+        if (stg + 1 < nst) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // C layout: col = lane&15 (kcol), row = (lane>>4)*4 + r (cout)
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+            const int kc = n0 + wn * TN + j * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = c0 + wm * TM + i * 16 + g * 4 + r;
+                if (co < a.Cout && kc < a.KTOT) unsafeAtomicAdd(&a.dw[(long)co * a.KTOT + kc], acc[i][j][r]);
+            }
+        }
+}
+
+template <typename T, int BMW, int BNW> static int launch_wgrad(const WgradArgs& a, int splits, hipStream_t st) {
+    constexpr int RSA = BMW * 2 + 32, RSB = BNW * 2 + 32;
+    const size_t smem = 2 * 64 * (RSA + RSB);
+    dim3 grid(cdiv(a.KTOT, BNW), cdiv(a.Cout, BMW), splits);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, BMW, BNW>), grid, dim3(256), smem, st, a);
+    return check_launch("conv_wgrad");
+}
+
+template <typename T> static int dispatch_wgrad(WgradArgs& a, int want_splits, hipStream_t st) {
+    const int bmw = a.Cout <= 32 ? 32 : (a.Cout <= 64 || a.Cout % 128 != 0 ? 64 : 128);
+    const int bnw = (a.KTOT <= 64 || (cdiv(a.KTOT, 128) * 128 - a.KTOT) > 32) ? 64 : 128;
+    const long tiles = (long)cdiv(a.KTOT, bnw) * cdiv(a.Cout, bmw);
+    int splits = want_splits;
+    if (splits <= 0) {
+        splits = (int)((1024 + tiles - 1) / tiles);  // ~4 blocks per CU in total
+        const int maxs = cdiv(a.M, 256);             // at least 256 pixels per split
+        if (splits > maxs) splits = maxs;
+        if (splits < 1) splits = 1;
+    }
+    a.chunk = cdiv(cdiv(a.M, splits), 64) * 64;
+    splits = cdiv(a.M, a.chunk);
+    if (bmw == 32) return bnw == 64 ? launch_wgrad<T, 32, 64>(a, splits, st) : launch_wgrad<T, 32, 128>(a, splits, st);
+    if (bmw == 64) return bnw == 64 ? launch_wgrad<T, 64, 64>(a, splits, st) : launch_wgrad<T, 64, 128>(a, splits, st);
+    return bnw == 64 ? launch_wgrad<T, 128, 64>(a, splits, st) : launch_wgrad<T, 128, 128>(a, splits, st);
+}
+
+}  // namespace fn
+
+using namespace fn;
+
+extern "C" int fn_conv2d_fwd(const fn_conv_desc* d, void* stream) {
+    if (int rc = check_desc(d)) return rc;
+    FN_REQUIRE(d->x && d->w && d->y, "conv_fwd: null x/w/y");
+    FN_REQUIRE(d->ld_y >= d->Cout && (d->out_f32 ? d->ld_y % 4 == 0 : d->ld_y % 8 == 0), "conv_fwd: ld_y=%d invalid", d->ld_y);
+    FN_REQUIRE(!d->resid || d->ld_res % 8 == 0, "conv_fwd: ld_res=%d invalid", d->ld_res);
+    ConvArgs a{};
+    a.src = (const unsigned short*)d->x; a.wp = (const unsigned short*)d->w; a.out = d->y;
+    a.bias = d->bias; a.stats = d->stats; a.resid = (const unsigned short*)d->resid;
+    a.M = d->N * d->OH * d->OW; a.PH = d->OH; a.PW = d->OW; a.SH = d->H; a.SW = d->W; a.CS = d->Cin;
+    a.NOUT = d->Cout; a.KTOT = d->KH * d->KW * d->Cin; a.KH = d->KH; a.KW = d->KW;
+    a.so = d->stride; a.sk = 1; a.offy = -d->pad_h; a.offx = -d->pad_w; a.dshift = 0;
+    a.ld_src = d->ld_x; a.ld_out = d->ld_y; a.ld_res = d->ld_res;
+    a.relu = d->relu; a.accumulate = d->accumulate; a.out_f32 = d->out_f32; a.scale = d->scale;
+    a.stats_sq_off = d->stats_sq_off;
+    return d->dtype == FN_BF16 ? dispatch_conv<__bf16>(a, (hipStream_t)stream) : dispatch_conv<_Float16>(a, (hipStream_t)stream);
+}
+
+// dX[n,iy,ix,ci] = sum_{ky,kx,co} dY[n,(iy+pad-ky)/s,(ix+pad-kx)/s,co] * Wt[ci][ky,kx][co]
+extern "C" int fn_conv2d_dgrad(const fn_conv_desc* d, void* stream) {
+    if (int rc = check_desc(d)) return rc;
+    FN_REQUIRE(d->y && d->w && d->dx, "conv_dgrad: null dy/wt/dx");
+    FN_REQUIRE(d->Cout % 8 == 0 && d->ld_y % 8 == 0 && d->ld_y >= d->Cout, "conv_dgrad: Cout=%d ld_y=%d must be multiples of 8", d->Cout,
+               d->ld_y);
+    ConvArgs a{};
+    a.src = (const unsigned short*)d->y; a.wp = (const unsigned short*)d->w; a.out = d->dx;
+    a.M = d->N * d->H * d->W; a.PH = d->H; a.PW = d->W; a.SH = d->OH; a.SW = d->OW; a.CS = d->Cout;
+    a.NOUT = d->Cin; a.KTOT = d->KH * d->KW * d->Cout; a.KH = d->KH; a.KW = d->KW;
+    a.so = 1; a.sk = -1; a.offy = d->pad_h; a.offx = d->pad_w; a.dshift = d->stride == 2 ? 1 : 0;
+    a.ld_src = d->ld_y; a.ld_out = d->ld_x; a.ld_res = 0;
+    a.relu = 0; a.accumulate = d->accumulate; a.out_f32 = d->out_f32; a.scale = 1.f;
+    return d->dtype == FN_BF16 ? dispatch_conv<__bf16>(a, (hipStream_t)stream) : dispatch_conv<_Float16>(a, (hipStream_t)stream);
+}
+
+extern "C" int fn_conv2d_wgrad(const fn_conv_desc* d, void* stream) {
+    if (int rc = check_desc(d)) return rc;
+    FN_REQUIRE(d->x && d->y && d->dw, "conv_wgrad: null x/dy/dw");
+    FN_REQUIRE(d->ld_y % 8 == 0 && d->ld_y >= d->Cout, "conv_wgrad: ld_y=%d invalid", d->ld_y);
+    FN_REQUIRE((long)d->N * d->OH * d->OW < (1L << 24), "conv_wgrad: N*OH*OW must be < 2^24");
+    WgradArgs a{};
+    a.x = (const unsigned short*)d->x; a.dy = (const unsigned short*)d->y; a.dw = d->dw;
+    a.M = d->N * d->OH * d->OW; a.OH = d->OH; a.OW = d->OW; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
+    a.KTOT = d->KH * d->KW * d->Cin; a.KW = d->KW; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
+    a.ld_x = d->ld_x; a.ld_y = d->ld_y;
+    a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0) ? 1 : 0;
+    a.inv_ow = 1.0f / (float)d->OW; a.inv_ohw = 1.0f / (float)(d->OH * d->OW);
+    return d->dtype == FN_BF16 ? dispatch_wgrad<__bf16>(a, d->splits, (hipStream_t)stream)
+                               : dispatch_wgrad<_Float16>(a, d->splits, (hipStream_t)stream);
+}

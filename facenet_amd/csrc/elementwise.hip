@@ -1,0 +1,620 @@
+// HBM-bound kernels around the convolutions: input normalisation, BatchNorm(+ReLU) train forward /
+// backward, pooling, residual backward, the fp32 embedding head.  All NHWC, 16 B (8 channels) per lane,
+// channel-slice aware (ld = channel stride of the enclosing concat buffer).
+#include "common.h"
+#include "../../include/facenet_hip.h"
+
+namespace fn {
+
+// ------------------------------------------------------------------------------------------------
+// ImageProcessing.call  (facenet/facenet.py:67-86)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f2ord(float f) {  // order-preserving float -> uint
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// work per image: [0]=ord(max) [1]=ord(-min) [2]=sum [3]=sumsq   (zeroed by a memset node first; ord(x) > 0 always)
+// SRC = uint8_t (the reference's 'input' node dtype, facenet/__init__.py:16-20) or float (facenet.py:69 casts anyway)
+template <typename SRC>
+__global__ __launch_bounds__(256) void img_stats_kernel(const SRC* __restrict__ img, unsigned* __restrict__ work, int count) {
+    const int n = blockIdx.y;
+    const SRC* p = img + (long)n * count;
+    float mx = -3e38f, mn = 3e38f, s = 0.f, q = 0.f;
+    constexpr int PER = 16 / sizeof(SRC);
+    const int nvec = count / PER;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(p + (long)i * PER);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if constexpr (sizeof(SRC) == 1) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float x = (float)((v[w] >> (8 * b)) & 0xffu);
+                    mx = fmaxf(mx, x); mn = fminf(mn, x); s += x; q += x * x;
+                }
+            } else {
+                const float x = __uint_as_float(v[w]);
+                mx = fmaxf(mx, x); mn = fminf(mn, x); s += x; q += x * x;
+            }
+        }
+    }
+    if (blockIdx.x == 0)
+        for (int i = nvec * PER + threadIdx.x; i < count; i += 256) {
+            const float x = (float)p[i];
+            mx = fmaxf(mx, x); mn = fminf(mn, x); s += x; q += x * x;
+        }
+    mx = wave_max(mx); mn = -wave_max(-mn); s = wave_sum(s); q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&work[4 * n + 0], f2ord(mx));
+        atomicMax(&work[4 * n + 1], f2ord(-mn));
+        atomicAdd(reinterpret_cast<float*>(&work[4 * n + 2]), s);
+        atomicAdd(reinterpret_cast<float*>(&work[4 * n + 3]), q);
+    }
+}
+
+template <typename T, typename SRC>
+__global__ __launch_bounds__(256) void img_apply_kernel(const SRC* __restrict__ img, unsigned short* __restrict__ out,
+                                                        const unsigned* __restrict__ work, int HW, int mode) {
+    const int n = blockIdx.y;
+    float a, b;  // y = a*x + b
+    if (mode == 0) {  // (2x - (min+max)) / max(max-min, 1e-3)   facenet.py:72-77
+        const float mx = ord2f(work[4 * n + 0]), mn = -ord2f(work[4 * n + 1]);
+        const float rng = fmaxf(mx - mn, 1e-3f);
+        a = 2.f / rng;
+        b = -(mn + mx) / rng;
+    } else {          // per_image_standardization: (x-mean)/max(std, 1/sqrt(numel))   facenet.py:79-80
+        const float cnt = (float)HW * 3.f;
+        const float mean = __uint_as_float(work[4 * n + 2]) / cnt;
+        const float var = fmaxf(__uint_as_float(work[4 * n + 3]) / cnt - mean * mean, 0.f);
+        const float sd = fmaxf(sqrtf(var), rsqrtf(cnt));
+        a = 1.f / sd;
+        b = -mean / sd;
+    }
+    const SRC* p = img + (long)n * HW * 3;
+    unsigned short* o = out + (long)n * HW * 8;
+    for (int px = blockIdx.x * 256 + threadIdx.x; px < HW; px += gridDim.x * 256) {
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = fmaf(a, (float)p[px * 3 + c], b);
+        *reinterpret_cast<u32x4*>(o + (long)px * 8) = pack8<T>(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_images_kernel(const uint8_t* __restrict__ pool, const int32_t* __restrict__ idx,
+                                                            uint8_t* __restrict__ out, int bytes) {
+    const int i = blockIdx.y;
+    const uint8_t* s = pool + (long)idx[i] * bytes;
+    uint8_t* d = out + (long)i * bytes;
+    const int nvec = bytes >> 4;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < nvec; k += gridDim.x * 256)
+        reinterpret_cast<u32x4*>(d)[k] = reinterpret_cast<const u32x4*>(s)[k];
+    if (blockIdx.x == 0)
+        for (int k = (nvec << 4) + threadIdx.x; k < bytes; k += 256) d[k] = s[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNormalization(center only) + ReLU, training mode.  y (raw conv output) is KEPT: the backward
+// needs xhat for every element, including the ones ReLU clamps.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* __restrict__ y, int ld_y, unsigned short* __restrict__ z,
+                                                          int ld_z, int M, int C, const float* __restrict__ stats, int sq_off,
+                                                          const float* __restrict__ beta, float* __restrict__ save_scale,
+                                                          float* __restrict__ save_shift, float* __restrict__ mm, float* __restrict__ mv,
+                                                          float momentum, float eps, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];  // scale[C], shift[C]
+    float* s_scale = sh;
+    float* s_shift = sh + C;
+    const float invM = 1.f / (float)M;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float mean = stats[c] * invM;
+        const float var = fmaxf(stats[sq_off + c] * invM - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + eps);
+        const float shf = beta[c] - mean * rstd;
+        s_scale[c] = rstd;
+        s_shift[c] = shf;
+        if (blockIdx.x == 0) {
+            save_scale[c] = rstd;
+            save_shift[c] = shf;
+            if (mm) {
+                mm[c] = mm[c] * momentum + mean * (1.f - momentum);
+                mv[c] = mv[c] * momentum + var * (1.f - momentum);  // biased variance (hazard 3)
+            }
+        }
+    }
+    __syncthreads();
+    const int CG = C >> 3;
+    const long total = (long)M * CG;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int row = (int)(t / CG), cg = (int)(t - (long)row * CG);
+        float v[8];
+        unpack8<T>(*reinterpret_cast<const u32x4*>(y + (long)row * ld_y + cg * 8), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float zf = fmaf(v[e], s_scale[cg * 8 + e], s_shift[cg * 8 + e]);
+            v[e] = relu ? fmaxf(zf, 0.f) : zf;
+        }
+        *reinterpret_cast<u32x4*>(z + (long)row * ld_z + cg * 8) = pack8<T>(v);
+    }
+}
+
+// pass 1: dbeta[c] += sum dyh, s2[c] += sum dyh*xhat, with zf = y*scale+shift, dyh = dz*(zf>0), xhat = zf - beta
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const unsigned short* __restrict__ dz, int ld_d,
+                                                                 const unsigned short* __restrict__ y, int ld_y, int M, int C,
+                                                                 const float* __restrict__ beta, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, float* __restrict__ dbeta,
+                                                                 float* __restrict__ s2, int relu, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];  // sdb[C], ss2[C]
+    float* sdb = sh;
+    float* ss2 = sh + C;
+    for (int c = threadIdx.x; c < 2 * C; c += 256) sh[c] = 0.f;
+    __syncthreads();
+    const int CG = C >> 3;
+    const int TX = CG > 16 ? 32 : (CG > 8 ? 16 : (CG > 4 ? 8 : 4));
+    const int TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    for (int cg = tx; cg < CG; cg += TX) {
+        float b[8], sc[8], sf[8], a1[8], a2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            b[e] = beta[cg * 8 + e]; sc[e] = scale[cg * 8 + e]; sf[e] = shift[cg * 8 + e];
+            a1[e] = 0.f; a2[e] = 0.f;
+        }
+        for (int r = r0 + ty; r < r1; r += TY) {
+            float g[8], yy[8];
+            unpack8<T>(*reinterpret_cast<const u32x4*>(dz + (long)r * ld_d + cg * 8), g);
+            unpack8<T>(*reinterpret_cast<const u32x4*>(y + (long)r * ld_y + cg * 8), yy);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float zf = fmaf(yy[e], sc[e], sf[e]);
+                const float gg = (!relu || zf > 0.f) ? g[e] : 0.f;
+                a1[e] += gg;
+                a2[e] += gg * (zf - b[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            atomicAdd(&sdb[cg * 8 + e], a1[e]);
+            atomicAdd(&ss2[cg * 8 + e], a2[e]);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomicAdd(&dbeta[c], sdb[c]);
+        atomicAdd(&s2[c], ss2[c]);
+    }
+}
+
+// pass 2: dy = rstd * (dyh - dbeta/M - xhat * s2/M) for EVERY element (masked ones included), in place over dz
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(unsigned short* __restrict__ dz, int ld_d,
+                                                                const unsigned short* __restrict__ y, int ld_y, int M, int C,
+                                                                const float* __restrict__ beta, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ dbeta,
+                                                                const float* __restrict__ s2, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];  // k1[C], k2[C], sc[C], sf[C], bt[C]
+    float* k1 = sh; float* k2 = sh + C; float* sc = sh + 2 * C; float* sf = sh + 3 * C; float* bt = sh + 4 * C;
+    const float invM = 1.f / (float)M;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        k1[c] = dbeta[c] * invM; k2[c] = s2[c] * invM; sc[c] = scale[c]; sf[c] = shift[c]; bt[c] = beta[c];
+    }
+    __syncthreads();
+    const int CG = C >> 3;
+    const long total = (long)M * CG;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int row = (int)(t / CG), cg = (int)(t - (long)row * CG);
+        unsigned short* p = dz + (long)row * ld_d + cg * 8;
+        float g[8], yy[8];
+        unpack8<T>(*reinterpret_cast<const u32x4*>(p), g);
+        unpack8<T>(*reinterpret_cast<const u32x4*>(y + (long)row * ld_y + cg * 8), yy);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cg * 8 + e;
+            const float zf = fmaf(yy[e], sc[c], sf[c]);
+            const float gg = (!relu || zf > 0.f) ? g[e] : 0.f;
+            g[e] = sc[c] * (gg - k1[c] - (zf - bt[c]) * k2[c]);
+        }
+        *reinterpret_cast<u32x4*>(p) = pack8<T>(g);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2D(3, strides=2, 'valid')
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* __restrict__ x, int ld_x, unsigned short* __restrict__ y,
+                                                          int ld_y, int N, int H, int W, int C, int OH, int OW) {
+    const int CG = C >> 3;
+    const long total = (long)N * OH * OW * CG;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int cg = (int)(t % CG);
+        long pix = t / CG;
+        const int ox = (int)(pix % OW); pix /= OW;
+        const int oy = (int)(pix % OH);
+        const int n = (int)(pix / OH);
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -3.0e38f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                float v[8];
+                unpack8<T>(*reinterpret_cast<const u32x4*>(x + ((long)(n * H + oy * 2 + ky) * W + ox * 2 + kx) * ld_x + cg * 8), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+        *reinterpret_cast<u32x4*>(y + ((long)(n * OH + oy) * OW + ox) * ld_y + cg * 8) = pack8<T>(m);
+    }
+}
+
+// gather form (deterministic, no atomics): input element (iy,ix) receives dy of every covering window whose
+// FIRST maximum (scan order ky, kx) sits at (iy,ix) -- the tie rule of tf/torch CPU max-pool gradients.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned short* __restrict__ x, int ld_x,
+                                                          const unsigned short* __restrict__ dy, int ld_dy,
+                                                          unsigned short* __restrict__ dx, int ld_dx, int N, int H, int W, int C, int OH,
+                                                          int OW, int accumulate) {
+    const int CG = C >> 3;
+    const long total = (long)N * H * W * CG;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int cg = (int)(t % CG);
+        long pix = t / CG;
+        const int ix = (int)(pix % W); pix /= W;
+        const int iy = (int)(pix % H);
+        const int n = (int)(pix / H);
+        float mine[8], g[8];
+        unpack8<T>(*reinterpret_cast<const u32x4*>(x + ((long)(n * H + iy) * W + ix) * ld_x + cg * 8), mine);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = 0.f;
+        const int oy_lo = max(0, (iy - 1) >> 1), oy_hi = min(OH - 1, iy >> 1);
+        const int ox_lo = max(0, (ix - 1) >> 1), ox_hi = min(OW - 1, ix >> 1);
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const int my = (iy - 2 * oy) * 3 + (ix - 2 * ox);  // my scan position in this window
+                bool win[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) win[e] = true;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    if (k == my) continue;
+                    float v[8];
+                    unpack8<T>(*reinterpret_cast<const u32x4*>(x + ((long)(n * H + 2 * oy + k / 3) * W + 2 * ox + k % 3) * ld_x + cg * 8), v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) win[e] = win[e] && (k < my ? (v[e] < mine[e]) : (v[e] <= mine[e]));
+                }
+                float d[8];
+                unpack8<T>(*reinterpret_cast<const u32x4*>(dy + ((long)(n * OH + oy) * OW + ox) * ld_dy + cg * 8), d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] += win[e] ? d[e] : 0.f;
+            }
+        unsigned short* o = dx + ((long)(n * H + iy) * W + ix) * ld_dx + cg * 8;
+        if (accumulate) {
+            float pv[8];
+            unpack8<T>(*reinterpret_cast<const u32x4*>(o), pv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] += pv[e];
+        }
+        *reinterpret_cast<u32x4*>(o) = pack8<T>(g);
+    }
+}
+
+// AvgPool2D over the whole HW map (3x3 -> 1x1 at 160x160, :460) + Flatten
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int N, int HW,
+                                                          int C) {
+    const int CG = C >> 3;
+    const int total = N * CG;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        const int n = t / CG, cg = t - n * CG;
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int p = 0; p < HW; ++p) {
+            float v[8];
+            unpack8<T>(*reinterpret_cast<const u32x4*>(x + ((long)n * HW + p) * C + cg * 8), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += v[e];
+        }
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] *= inv;
+        *reinterpret_cast<u32x4*>(y + (long)n * C + cg * 8) = pack8<T>(s);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const unsigned short* __restrict__ dy, unsigned short* __restrict__ dx, int N, int HW,
+                                                          int C) {
+    const int CG = C >> 3;
+    const int total = N * CG;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        const int n = t / CG, cg = t - n * CG;
+        float v[8];
+        unpack8<T>(*reinterpret_cast<const u32x4*>(dy + (long)n * C + cg * 8), v);
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= inv;
+        const u32x4 pk = pack8<T>(v);
+        for (int p = 0; p < HW; ++p) *reinterpret_cast<u32x4*>(dx + ((long)n * HW + p) * C + cg * 8) = pk;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// residual backward:  out = act(trunk + scale*(up + bias))
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void residual_bwd_kernel(const unsigned short* __restrict__ dout, const unsigned short* __restrict__ out,
+                                                           unsigned short* __restrict__ dtrunk, unsigned short* __restrict__ dup,
+                                                           float* __restrict__ dbias, int M, int C, float scale, int relu, int accumulate,
+                                                           int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];  // sdb[C]
+    for (int c = threadIdx.x; c < C; c += 256) sh[c] = 0.f;
+    __syncthreads();
+    const int CG = C >> 3;
+    const int TX = 32, TY = 8;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int cg = tx; cg < CG; cg += TX) {
+        float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = r0 + ty; r < r1; r += TY) {
+            const long o = (long)r * C + cg * 8;
+            float g[8], zz[8], u[8];
+            unpack8<T>(*reinterpret_cast<const u32x4*>(dout + o), g);
+            if (relu) {
+                unpack8<T>(*reinterpret_cast<const u32x4*>(out + o), zz);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { u[e] = scale * g[e]; a1[e] += u[e]; }
+            *reinterpret_cast<u32x4*>(dup + o) = pack8<T>(u);
+            if (accumulate) {
+                float pv[8];
+                unpack8<T>(*reinterpret_cast<const u32x4*>(dtrunk + o), pv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] += pv[e];
+            }
+            *reinterpret_cast<u32x4*>(dtrunk + o) = pack8<T>(g);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(&sh[cg * 8 + e], a1[e]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(&dbias[c], sh[c]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding head (fp32 [N,E]): BatchNorm without ReLU, l2_normalize
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void head_bn_fwd_kernel(const float* __restrict__ y, float* __restrict__ out, int N, int E,
+                                                         const float* __restrict__ beta, float* __restrict__ mm, float* __restrict__ mv,
+                                                         float* __restrict__ save_mean, float* __restrict__ save_rstd, int training,
+                                                         float momentum, float eps) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= E) return;
+    float mean, var;
+    if (training) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += y[(long)n * E + c];
+        mean = s / (float)N;
+        float q = 0.f;
+        for (int n = 0; n < N; ++n) { const float d = y[(long)n * E + c] - mean; q += d * d; }
+        var = q / (float)N;
+        mm[c] = mm[c] * momentum + mean * (1.f - momentum);
+        mv[c] = mv[c] * momentum + var * (1.f - momentum);
+    } else {
+        mean = mm[c];
+        var = mv[c];
+    }
+    const float rstd = rsqrtf(var + eps);
+    if (save_mean) { save_mean[c] = mean; save_rstd[c] = rstd; }
+    const float b = beta[c];
+    for (int n = 0; n < N; ++n) out[(long)n * E + c] = (y[(long)n * E + c] - mean) * rstd + b;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void head_bn_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                         const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                                         float* __restrict__ dbeta, unsigned short* __restrict__ dy, int N, int E) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= E) return;
+    const float mean = save_mean[c], rstd = save_rstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float g = dout[(long)n * E + c];
+        s1 += g;
+        s2 += g * (y[(long)n * E + c] - mean) * rstd;
+    }
+    dbeta[c] += s1;
+    const float k1 = s1 / (float)N, k2 = s2 / (float)N;
+    for (int n = 0; n < N; ++n) {
+        const float xh = (y[(long)n * E + c] - mean) * rstd;
+        dy[(long)n * E + c] = LP<T>::from_f32(rstd * (dout[(long)n * E + c] - k1 - xh * k2));
+    }
+}
+
+// one wave per row: out = x * rsqrt(max(sum x^2, eps))   (tf.nn.l2_normalize, :491-492)
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int E, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    float s = 0.f;
+    for (int k = lane; k < E; k += 64) { const float v = x[(long)row * E + k]; s += v * v; }
+    s = wave_sum(s);
+    const float r = rsqrtf(fmaxf(s, eps));
+    for (int k = lane; k < E; k += 64) out[(long)row * E + k] = x[(long)row * E + k] * r;
+}
+// dx = r*(dout - xn * <dout, xn>) with xn = x*r (the eps clamp branch has zero derivative through r)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, float* __restrict__ dx,
+                                                         int N, int E, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    float s = 0.f, d = 0.f;
+    for (int k = lane; k < E; k += 64) {
+        const float v = x[(long)row * E + k];
+        s += v * v;
+        d += v * dout[(long)row * E + k];
+    }
+    s = wave_sum(s);
+    d = wave_sum(d);
+    const bool clamped = s < eps;
+    const float r = rsqrtf(fmaxf(s, eps));
+    for (int k = lane; k < E; k += 64) {
+        const float v = x[(long)row * E + k];
+        dx[(long)row * E + k] = clamped ? r * dout[(long)row * E + k] : r * (dout[(long)row * E + k] - v * r * r * d);
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = LP<T>::from_f32(x[i]);
+}
+
+static inline int grid_for(long work_items, int per_block = 256, int cap = 4096) {
+    long g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace fn
+
+using namespace fn;
+#define DT_CHECK(dt) FN_REQUIRE((dt) == FN_BF16 || (dt) == FN_F16, "dtype %d unsupported", (dt))
+#define LAUNCH_T(dt, KERN, grid, block, smem, st, ...)                                             \
+    do {                                                                                             \
+        if ((dt) == FN_BF16) hipLaunchKernelGGL(KERN<__bf16>, grid, block, smem, st, __VA_ARGS__);   \
+        else hipLaunchKernelGGL(KERN<_Float16>, grid, block, smem, st, __VA_ARGS__);                 \
+    } while (0)
+
+template <typename SRC>
+static int image_normalize_impl(const SRC* img, void* out, float* work, int N, int HW, int mode, int dtype, void* stream) {
+    DT_CHECK(dtype);
+    FN_REQUIRE(img && out && work && N > 0 && HW > 0, "image_normalize: bad arguments");
+    FN_REQUIRE(mode == 0 || mode == 1, "Invalid image normalization algorithm");  // facenet.py:82
+    FN_REQUIRE(((uintptr_t)img & 15) == 0 && ((long)HW * 3 * sizeof(SRC)) % 16 == 0, "image_normalize: images must be 16-B aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(work, 0, sizeof(float) * 4 * N, st) != hipSuccess) { set_error("image_normalize: memset failed"); return FN_ELAUNCH; }
+    hipLaunchKernelGGL(img_stats_kernel<SRC>, dim3(8, N), dim3(256), 0, st, img, (unsigned*)work, HW * 3);
+    const int gx = grid_for(HW, 256, 32);
+    if (dtype == FN_BF16) hipLaunchKernelGGL((img_apply_kernel<__bf16, SRC>), dim3(gx, N), dim3(256), 0, st, img, (unsigned short*)out, (const unsigned*)work, HW, mode);
+    else hipLaunchKernelGGL((img_apply_kernel<_Float16, SRC>), dim3(gx, N), dim3(256), 0, st, img, (unsigned short*)out, (const unsigned*)work, HW, mode);
+    return check_launch("image_normalize");
+}
+extern "C" int fn_image_normalize(const uint8_t* img, void* out, float* work, int N, int HW, int mode, int dtype, void* stream) {
+    return image_normalize_impl<uint8_t>(img, out, work, N, HW, mode, dtype, stream);
+}
+extern "C" int fn_image_normalize_f32(const float* img, void* out, float* work, int N, int HW, int mode, int dtype, void* stream) {
+    return image_normalize_impl<float>(img, out, work, N, HW, mode, dtype, stream);
+}
+
+extern "C" int fn_gather_images(const uint8_t* pool, const int32_t* idx, uint8_t* out, int n_out, int bytes, void* stream) {
+    FN_REQUIRE(pool && idx && out && n_out > 0 && bytes > 0 && bytes % 16 == 0, "gather_images: bad arguments");
+    hipLaunchKernelGGL(gather_images_kernel, dim3(8, n_out), dim3(256), 0, (hipStream_t)stream, pool, idx, out, bytes);
+    return check_launch("gather_images");
+}
+
+extern "C" int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, int M, int C, const float* stats, int stats_sq_off,
+                                    const float* beta,
+                                    float* save_scale, float* save_shift, float* moving_mean, float* moving_var, float momentum, float eps,
+                                    int relu, int dtype, void* stream) {
+    DT_CHECK(dtype);
+    FN_REQUIRE(y && z && stats && beta && save_scale && save_shift && M > 0 && C > 0 && C % 8 == 0 && ld_y % 8 == 0 && ld_z % 8 == 0 &&
+                   ld_y >= C && ld_z >= C && C <= 8192, "bn_fwd: bad arguments");
+    const int grid = grid_for((long)M * (C / 8), 256, 2048);
+    const size_t sm = 2 * C * sizeof(float);
+    LAUNCH_T(dtype, bn_relu_fwd_kernel, dim3(grid), dim3(256), sm, (hipStream_t)stream, (const unsigned short*)y, ld_y, (unsigned short*)z, ld_z, M, C, stats, stats_sq_off, beta, save_scale, save_shift, moving_mean, moving_var, momentum, eps, relu);
+    return check_launch("bn_relu_fwd");
+}
+
+extern "C" int fn_bn_relu_train_bwd(void* dz, int ld_d, const void* y, int ld_y, int M, int C, const float* beta, const float* save_scale,
+                                    const float* save_shift, float* dbeta, float* s2, int relu, int dtype, void* stream) {
+    DT_CHECK(dtype);
+    FN_REQUIRE(dz && y && beta && save_scale && save_shift && dbeta && s2 && M > 0 && C > 0 && C % 8 == 0 && ld_d % 8 == 0 &&
+                   ld_y % 8 == 0 && C <= 4096, "bn_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int rpb = cdiv(M, 1024);
+    if (rpb < 8) rpb = 8;
+    const int g1 = cdiv(M, rpb);
+    const int g2 = grid_for((long)M * (C / 8), 256, 2048);
+    LAUNCH_T(dtype, bn_relu_bwd_reduce_kernel, dim3(g1), dim3(256), 2 * C * sizeof(float), st, (const unsigned short*)dz, ld_d, (const unsigned short*)y, ld_y, M, C, beta, save_scale, save_shift, dbeta, s2, relu, rpb);
+    LAUNCH_T(dtype, bn_relu_bwd_apply_kernel, dim3(g2), dim3(256), 5 * C * sizeof(float), st, (unsigned short*)dz, ld_d, (const unsigned short*)y, ld_y, M, C, beta, save_scale, save_shift, dbeta, s2, relu);
+    return check_launch("bn_relu_bwd");
+}
+
+extern "C" int fn_maxpool3x3s2_fwd(const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, int dtype, void* stream) {
+    DT_CHECK(dtype);
+    FN_REQUIRE(x && y && N > 0 && H >= 3 && W >= 3 && C % 8 == 0 && ld_x % 8 == 0 && ld_y % 8 == 0, "maxpool_fwd: bad arguments");
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+    const int grid = grid_for((long)N * OH * OW * (C / 8));
+    LAUNCH_T(dtype, maxpool_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, ld_x, (unsigned short*)y, ld_y, N, H, W, C, OH, OW);
+    return check_launch("maxpool_fwd");
+}
+
+extern "C" int fn_maxpool3x3s2_bwd(const void* x, int ld_x, const void* dy, int ld_dy, void* dx, int ld_dx, int N, int H, int W, int C,
+                                   int accumulate, int dtype, void* stream) {
+    DT_CHECK(dtype);
+    FN_REQUIRE(x && dy && dx && N > 0 && H >= 3 && W >= 3 && C % 8 == 0 && ld_x % 8 == 0 && ld_dy % 8 == 0 && ld_dx % 8 == 0,
+               "maxpool_bwd: bad arguments");
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+    const int grid = grid_for((long)N * H * W * (C / 8));
+    LAUNCH_T(dtype, maxpool_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, ld_x, (const unsigned short*)dy, ld_dy, (unsigned short*)dx, ld_dx, N, H, W, C, OH, OW, accumulate);
+    return check_launch("maxpool_bwd");
+}
+
+extern "C" int fn_avgpool_fwd(const void* x, void* y, int N, int HW, int C, int dtype, void* stream) {
+    DT_CHECK(dtype);
+    FN_REQUIRE(x && y && N > 0 && HW > 0 && C % 8 == 0, "avgpool_fwd: bad arguments");
+    LAUNCH_T(dtype, avgpool_fwd_kernel, dim3(grid_for((long)N * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)y, N, HW, C);
+    return check_launch("avgpool_fwd");
+}
+extern "C" int fn_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype, void* stream) {
+    DT_CHECK(dtype);
+    FN_REQUIRE(dy && dx && N > 0 && HW > 0 && C % 8 == 0, "avgpool_bwd: bad arguments");
+    LAUNCH_T(dtype, avgpool_bwd_kernel, dim3(grid_for((long)N * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy, (unsigned short*)dx, N, HW, C);
+    return check_launch("avgpool_bwd");
+}
+
+extern "C" int fn_residual_bwd(const void* dout, const void* out, void* dtrunk, void* dup, float* dbias, int M, int C, float scale, int relu,
+                               int accumulate, int dtype, void* stream) {
+    DT_CHECK(dtype);
+    FN_REQUIRE(dout && dtrunk && dup && dbias && (out || !relu) && M > 0 && C > 0 && C % 8 == 0 && C <= 8192, "residual_bwd: bad arguments");
+    int rpb = cdiv(M, 1024);
+    if (rpb < 8) rpb = 8;
+    LAUNCH_T(dtype, residual_bwd_kernel, dim3(cdiv(M, rpb)), dim3(256), C * sizeof(float), (hipStream_t)stream, (const unsigned short*)dout, (const unsigned short*)out, (unsigned short*)dtrunk, (unsigned short*)dup, dbias, M, C, scale, relu, accumulate, rpb);
+    return check_launch("residual_bwd");
+}
+
+extern "C" int fn_head_bn_fwd(const float* y, float* out, int N, int E, const float* beta, float* moving_mean, float* moving_var,
+                              float* save_mean, float* save_rstd, int training, float momentum, float eps, void* stream) {
+    FN_REQUIRE(y && out && beta && moving_mean && moving_var && N > 0 && E > 0, "head_bn_fwd: bad arguments");
+    hipLaunchKernelGGL(head_bn_fwd_kernel, dim3(cdiv(E, 64)), dim3(64), 0, (hipStream_t)stream, y, out, N, E, beta, moving_mean, moving_var,
+                       save_mean, save_rstd, training, momentum, eps);
+    return check_launch("head_bn_fwd");
+}
+extern "C" int fn_head_bn_bwd(const float* dout, const float* y, const float* save_mean, const float* save_rstd, float* dbeta, void* dy_lp,
+                              int N, int E, int dtype, void* stream) {
+    DT_CHECK(dtype);
+    FN_REQUIRE(dout && y && save_mean && save_rstd && dbeta && dy_lp && N > 0 && E > 0, "head_bn_bwd: bad arguments");
+    LAUNCH_T(dtype, head_bn_bwd_kernel, dim3(cdiv(E, 64)), dim3(64), 0, (hipStream_t)stream, dout, y, save_mean, save_rstd, dbeta, (unsigned short*)dy_lp, N, E);
+    return check_launch("head_bn_bwd");
+}
+extern "C" int fn_l2norm_fwd(const float* x, float* out, int N, int E, float eps, void* stream) {
+    FN_REQUIRE(x && out && N > 0 && E > 0, "l2norm_fwd: bad arguments");
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, x, out, N, E, eps);
+    return check_launch("l2norm_fwd");
+}
+extern "C" int fn_l2norm_bwd(const float* x, const float* dout, float* dx, int N, int E, float eps, void* stream) {
+    FN_REQUIRE(x && dout && dx && N > 0 && E > 0, "l2norm_bwd: bad arguments");
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, x, dout, dx, N, E, eps);
+    return check_launch("l2norm_bwd");
+}
+extern "C" int fn_cast_f32_to_lp(const float* x, void* y, long n, int dtype, void* stream) {
+    DT_CHECK(dtype);
+    FN_REQUIRE(x && y && n > 0, "cast: bad arguments");
+    LAUNCH_T(dtype, cast_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)y, n);
+    return check_launch("cast");
+}

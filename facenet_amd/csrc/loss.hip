@@ -1,0 +1,285 @@
+// Distance matrix, online triplet selection, triplet loss, softmax cross-entropy.
+//  * fn_pairwise_sqdist restates facenet/statistics.py:22-57 (pairwise_similarities) on device:
+//    one wave per (row i, block of columns), dot products by wavefront reduction.
+//  * triplet selection / loss are build-defined (arXiv 1503.03832 sec. 3); the
+//    counter-based hash below is shared bit-for-bit with oracle/facenet_oracle.py:hash_u32 so the
+//    selected indices can be compared exactly.
+//  * softmax cross-entropy = SparseCategoricalCrossentropy(from_logits=True), apps/train_softmax.py:91.
+#include "common.h"
+#include "../../include/facenet_hip.h"
+
+namespace fn {
+
+__device__ __forceinline__ int f2ord_i(float f) {  // order-preserving float -> int
+    int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+
+// out[i][j] for i<n, j<m ; range[0]=ord(min dot) via atomicMin, range[1]=ord(max dot) via atomicMax
+__global__ __launch_bounds__(256) void pairwise_kernel(const float* __restrict__ xa, const float* __restrict__ xb, float* __restrict__ out,
+                                                       int* __restrict__ range, int n, int m, int E, int metric) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.y;
+    const int jb = (blockIdx.x * 4 + wave) * 16;
+    if (jb >= m) return;
+    // this lane's slice of row i stays in registers (E <= 64*8)
+    float a[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) a[t] = (lane + 64 * t < E) ? xa[(long)i * E + lane + 64 * t] : 0.f;
+    float asq = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) asq += a[t] * a[t];
+    asq = wave_sum(asq);
+    float lo = 3e38f, hi = -3e38f;
+    for (int j = jb; j < min(m, jb + 16); ++j) {
+        float d = 0.f, bsq = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (lane + 64 * t < E) {
+                const float b = xb[(long)j * E + lane + 64 * t];
+                d += a[t] * b;
+                bsq += b * b;
+            }
+        d = wave_sum(d);
+        float r;
+        if (metric == 2) {
+            bsq = wave_sum(bsq);
+            r = fmaxf(asq + bsq - 2.f * d, 0.f);
+        } else {
+            lo = fminf(lo, d);
+            hi = fmaxf(hi, d);
+            const float s = fminf(fmaxf(d, -1.f), 1.f);   // statistics.py:45-46
+            r = (metric == 0) ? 2.f * (1.f - s) : acosf(s);  // :48-53
+        }
+        if (lane == 0) out[(long)i * m + j] = r;
+    }
+    if (range && lane == 0 && metric != 2) {
+        atomicMin(&range[0], f2ord_i(lo));
+        atomicMax(&range[1], f2ord_i(hi));
+    }
+}
+
+__device__ __forceinline__ unsigned hash_mix(unsigned h, unsigned v) {
+    h ^= v;
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ unsigned hash_u32(unsigned a, unsigned b, unsigned c) {
+    return hash_mix(hash_mix(hash_mix(0x9E3779B9u, a), b), c);
+}
+
+// Single workgroup; n <= 1024.  scratch (int32, global): per pair q: [a, p, neg, key(u32), cls] at scratch[8 + 5*q].
+// info[0] = #pairs, info[1] = #valid (candidate found), info[2] = 1 if fewer pairs than requested triplets,
+// info[3] = call counter: the effective seed is seed + info[3], so a HIP-graph replay (frozen kernel arguments)
+// still draws fresh negatives every step.  The caller zeroes info once.
+__global__ __launch_bounds__(1024) void select_triplets_kernel(const float* __restrict__ dist, const int* __restrict__ labels, int n,
+                                                               float alpha, int T, unsigned seed0, int semi_hard,
+                                                               int* __restrict__ triplets, int* __restrict__ info) {
+    const unsigned seed = seed0 + (unsigned)info[3];
+    __shared__ int s_lab[1024];
+    __shared__ int s_off[1025];
+    __shared__ int s_nvalid;
+    const int tid = threadIdx.x;
+    int* rec = info + 8;
+    if (tid == 0) s_nvalid = 0;
+    for (int i = tid; i < n; i += 1024) s_lab[i] = labels[i];
+    __syncthreads();
+    // pairs per anchor (a < p, same label), exclusive prefix -> pair ids in row-major order
+    int cnt = 0;
+    if (tid < n)
+        for (int p = tid + 1; p < n; ++p) cnt += (s_lab[p] == s_lab[tid]);
+    if (tid < n) s_off[tid + 1] = cnt;
+    if (tid == 0) s_off[0] = 0;
+    __syncthreads();
+    if (tid == 0)
+        for (int i = 0; i < n; ++i) s_off[i + 1] += s_off[i];
+    __syncthreads();
+    const int Q = s_off[n];
+    if (tid < n) {
+        const int a = tid;
+        int q = s_off[a];
+        for (int p = a + 1; p < n; ++p) {
+            if (s_lab[p] != s_lab[a]) continue;
+            const float dap = dist[(long)a * n + p];
+            int c = 0, others = 0;
+            for (int j = 0; j < n; ++j) {
+                if (s_lab[j] == s_lab[a]) continue;
+                ++others;
+                const float daj = dist[(long)a * n + j];
+                c += ((daj - dap < alpha) && (!semi_hard || daj > dap)) ? 1 : 0;
+            }
+            int neg = -1, cls = 1;
+            if (c > 0) {
+                int want = (int)(hash_u32(seed, (unsigned)q, 0u) % (unsigned)c);
+                for (int j = 0; j < n; ++j) {
+                    if (s_lab[j] == s_lab[a]) continue;
+                    const float daj = dist[(long)a * n + j];
+                    if ((daj - dap < alpha) && (!semi_hard || daj > dap)) {
+                        if (want == 0) { neg = j; break; }
+                        --want;
+                    }
+                }
+                cls = 0;
+                atomicAdd(&s_nvalid, 1);
+            } else if (others > 0) {
+                int want = (int)(hash_u32(seed, (unsigned)q, 2u) % (unsigned)others);
+                for (int j = 0; j < n; ++j) {
+                    if (s_lab[j] == s_lab[a]) continue;
+                    if (want == 0) { neg = j; break; }
+                    --want;
+                }
+            }
+            rec[5 * q + 0] = a;
+            rec[5 * q + 1] = p;
+            rec[5 * q + 2] = neg;
+            rec[5 * q + 3] = (int)hash_u32(seed, (unsigned)q, 1u);
+            rec[5 * q + 4] = cls;
+            ++q;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();  // single workgroup: the records above are visible to every wave after the fence + barrier
+    // rank by (cls, key, q); rank < T wins slot `rank`
+    for (int q = tid; q < Q; q += 1024) {
+        const int cls = rec[5 * q + 4];
+        const unsigned key = (unsigned)rec[5 * q + 3];
+        int rank = 0;
+        for (int r = 0; r < Q; ++r) {
+            const int c2 = rec[5 * r + 4];
+            const unsigned k2 = (unsigned)rec[5 * r + 3];
+            const bool before = (c2 < cls) || (c2 == cls && (k2 < key || (k2 == key && r < q)));
+            rank += before ? 1 : 0;
+        }
+        if (rank < T && rec[5 * q + 2] >= 0) {
+            triplets[3 * rank + 0] = rec[5 * q + 0];
+            triplets[3 * rank + 1] = rec[5 * q + 1];
+            triplets[3 * rank + 2] = rec[5 * q + 2];
+        }
+    }
+    if (tid == 0) {
+        info[0] = Q;
+        info[1] = s_nvalid;
+        info[2] = (Q < T) ? 1 : 0;
+        info[3] = (int)(seed - seed0) + 1;
+    }
+}
+
+// emb rows (a0,p0,n0,a1,...), fp32 [3T,E].  One wave per triplet.
+__global__ __launch_bounds__(256) void triplet_loss_kernel(const float* __restrict__ emb, float* __restrict__ demb, float* __restrict__ loss,
+                                                           int T, int E, float alpha) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= T) return;
+    const float* a = emb + (long)(3 * t) * E;
+    const float* p = a + E;
+    const float* ng = p + E;
+    float pos = 0.f, neg = 0.f;
+    for (int k = lane; k < E; k += 64) {
+        const float dp = a[k] - p[k], dn = a[k] - ng[k];
+        pos += dp * dp;
+        neg += dn * dn;
+    }
+    pos = wave_sum(pos);
+    neg = wave_sum(neg);
+    const float l = pos - neg + alpha;
+    const float on = l > 0.f ? 1.f : 0.f;
+    if (lane == 0) atomicAdd(loss, fmaxf(l, 0.f) / (float)T);
+    if (demb) {
+        const float s = 2.f * on / (float)T;
+        float* da = demb + (long)(3 * t) * E;
+        for (int k = lane; k < E; k += 64) {
+            da[k] = s * (ng[k] - p[k]);
+            da[E + k] = s * (p[k] - a[k]);
+            da[2 * E + k] = s * (a[k] - ng[k]);
+        }
+    }
+}
+
+// one workgroup per row: loss += (lse - logit[label])/N ; dlogits = (softmax - onehot) * grad_scale (low precision, padded cols = 0)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits, int ld, const int* __restrict__ labels,
+                                                           float* __restrict__ loss, unsigned short* __restrict__ dlogits, int ld_d,
+                                                           float* __restrict__ dbias, int N, int C, float grad_scale) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = logits + (long)row * ld;
+    float mx = -3e38f;
+    for (int c = tid; c < C; c += 256) mx = fmaxf(mx, x[c]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = tid; c < C; c += 256) s += __expf(x[c] - mx);
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = red[0] + red[1] + red[2] + red[3];
+    const int lab = labels[row];
+    if (tid == 0) atomicAdd(loss, (logf(s) + mx - x[lab]) / (float)N);
+    if (dlogits) {
+        const float inv = 1.f / s;
+        unsigned short* d = dlogits + (long)row * ld_d;
+        for (int c = tid; c < ld_d; c += 256) {
+            float g = 0.f;
+            if (c < C) {
+                g = (__expf(x[c] - mx) * inv - (c == lab ? 1.f : 0.f)) * grad_scale;
+                if (dbias) atomicAdd(&dbias[c], g);
+            }
+            d[c] = LP<T>::from_f32(g);
+        }
+    }
+}
+
+}  // namespace fn
+using namespace fn;
+
+extern "C" int fn_pairwise_sqdist(const float* xa, const float* xb, float* out, float* range, int n, int m, int E, int metric, void* stream) {
+    FN_REQUIRE(xa && xb && out && n > 0 && m > 0 && E > 0 && E <= 512, "pairwise_sqdist: bad arguments (E must be <= 512)");
+    FN_REQUIRE(metric >= 0 && metric <= 2, "Undefined similarity metric %d", metric);  // statistics.py:55
+    hipStream_t st = (hipStream_t)stream;
+    if (range) {
+        const int init[2] = {0x7f7fffff, (int)0x80800000};  // ord(+FLT_MAX), ord(-FLT_MAX)
+        // two 4-byte memsets keep the call capturable (no host staging buffer)
+        if (hipMemsetD32Async((hipDeviceptr_t)range, init[0], 1, st) != hipSuccess ||
+            hipMemsetD32Async((hipDeviceptr_t)((int*)range + 1), init[1], 1, st) != hipSuccess) {
+            set_error("pairwise_sqdist: memset failed");
+            return FN_ELAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(pairwise_kernel, dim3(cdiv(m, 64), n), dim3(256), 0, st, xa, xb, out, (int*)range, n, m, E, metric);
+    return check_launch("pairwise_sqdist");
+}
+
+extern "C" int fn_select_triplets(const float* dist, const int32_t* labels, int n, float alpha, int nrof_triplets, uint32_t seed,
+                                  int semi_hard, int32_t* triplets, int32_t* info, void* stream) {
+    FN_REQUIRE(dist && labels && triplets && info && n > 1 && n <= 1024 && nrof_triplets > 0, "select_triplets: bad arguments (n <= 1024)");
+    hipLaunchKernelGGL(select_triplets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dist, labels, n, alpha, nrof_triplets, seed,
+                       semi_hard, triplets, info);
+    return check_launch("select_triplets");
+}
+
+extern "C" int fn_triplet_loss_fwd_bwd(const float* emb, float* demb, float* loss, int T, int E, float alpha, void* stream) {
+    FN_REQUIRE(emb && loss && T > 0 && E > 0, "triplet_loss: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) { set_error("triplet_loss: memset failed"); return FN_ELAUNCH; }
+    hipLaunchKernelGGL(triplet_loss_kernel, dim3(cdiv(T, 4)), dim3(256), 0, st, emb, demb, loss, T, E, alpha);
+    return check_launch("triplet_loss");
+}
+
+extern "C" int fn_softmax_xent_fwd_bwd(const float* logits, int ld, const int32_t* labels, float* loss, void* dlogits_lp, int ld_d, float* dbias,
+                                       int N, int C, float grad_scale, int dtype, void* stream) {
+    FN_REQUIRE(dtype == FN_BF16 || dtype == FN_F16, "dtype %d unsupported", dtype);
+    FN_REQUIRE(logits && labels && loss && N > 0 && C > 0 && ld >= C && (!dlogits_lp || ld_d >= C), "softmax_xent: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) { set_error("softmax_xent: memset failed"); return FN_ELAUNCH; }
+    if (dtype == FN_BF16)
+        hipLaunchKernelGGL(softmax_xent_kernel<__bf16>, dim3(N), dim3(256), 0, st, logits, ld, labels, loss, (unsigned short*)dlogits_lp, ld_d, dbias, N, C, grad_scale);
+    else
+        hipLaunchKernelGGL(softmax_xent_kernel<_Float16>, dim3(N), dim3(256), 0, st, logits, ld, labels, loss, (unsigned short*)dlogits_lp, ld_d, dbias, N, C, grad_scale);
+    return check_launch("softmax_xent");
+}

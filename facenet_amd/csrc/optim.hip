@@ -1,0 +1,132 @@
+// Optimiser and weight packs.
+//  * fn_adam_keras: tf.keras.optimizers.Adam(epsilon=0.1) exactly as Keras applies it
+//    (apps/train_softmax.py:92; SURVEY.md hazard 8): lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
+//    w -= lr_t*m/(sqrt(v)+eps), with the Keras L2(5e-4) kernel regulariser (inception_resnet_v1.py:65)
+//    folded in as a coupled term g += 2*l2*w on the first n_decay elements.  One fused multi-tensor
+//    pass over the flat parameter buffer also emits the low-precision weight copy the MFMA kernels read.
+//  * fn_pack_transpose: [Cout][tap][Cin] -> [Cin][tap][Cout] (operand of the dgrad implicit GEMM).
+//  * fn_fold_bn: inference weights with BatchNorm folded in, the formula of facenet/tfutils.py:244-250.
+#include "common.h"
+#include "../../include/facenet_hip.h"
+
+namespace fn {
+
+// hyper: [0]=lr [1]=beta1^t [2]=beta2^t [3]=grad_scale ; powers are those AFTER this step's tick
+template <typename T>
+__global__ __launch_bounds__(256) void adam_keras_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, unsigned short* __restrict__ w_lp, long n_lp, long n, long n_decay,
+                                                         const float* __restrict__ hyper, float beta1, float beta2, float eps, float l2) {
+    const float lr = hyper[0], b1t = hyper[1], b2t = hyper[2], gs = hyper[3];
+    const float lr_t = lr * sqrtf(1.f - b2t) / (1.f - b1t);
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 wv = reinterpret_cast<f32x4*>(w)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float gg = gv[e] * gs;
+            if (i * 4 + e < n_decay) gg += 2.f * l2 * wv[e];
+            mv[e] = beta1 * mv[e] + (1.f - beta1) * gg;
+            vv[e] = beta2 * vv[e] + (1.f - beta2) * gg * gg;
+            wv[e] -= lr_t * mv[e] / (sqrtf(vv[e]) + eps);
+        }
+        reinterpret_cast<f32x4*>(w)[i] = wv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+        if (w_lp && i * 4 < n_lp) {
+            const unsigned lo = (unsigned)LP<T>::from_f32(wv[0]) | ((unsigned)LP<T>::from_f32(wv[1]) << 16);
+            const unsigned hi = (unsigned)LP<T>::from_f32(wv[2]) | ((unsigned)LP<T>::from_f32(wv[3]) << 16);
+            reinterpret_cast<uint2*>(w_lp)[i] = make_uint2(lo, hi);
+        }
+    }
+}
+
+__global__ void adam_tick_kernel(float* hyper, float beta1, float beta2) {
+    hyper[1] *= beta1;
+    hyper[2] *= beta2;
+}
+
+// one workgroup column (blockIdx.y = layer); table row = {w_off, cout, ktot, taps, cin, bn_off, fold_bias_off, 0}
+template <typename T>
+__global__ __launch_bounds__(256) void pack_transpose_kernel(const unsigned short* __restrict__ w, unsigned short* __restrict__ wt,
+                                                             const int* __restrict__ table) {
+    const int* row = table + 8 * blockIdx.y;
+    const long off = row[0];
+    const int cout = row[1], ktot = row[2], taps = row[3], cin = row[4];
+    const long total = (long)cout * ktot;
+    // destination-linear so the stores coalesce: dst[(ci*taps + tap)*cout + co] = src[(co*taps + tap)*cin + ci]
+    for (long d = (long)blockIdx.x * 256 + threadIdx.x; d < total; d += (long)gridDim.x * 256) {
+        const int co = (int)(d % cout);
+        const long r = d / cout;
+        const int tap = (int)(r % taps), ci = (int)(r / taps);
+        wt[off + d] = w[off + ((long)co * taps + tap) * cin + ci];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fold_bn_kernel(const float* __restrict__ w, unsigned short* __restrict__ wf, float* __restrict__ fold_bias,
+                                                      const float* __restrict__ beta, const float* __restrict__ mm,
+                                                      const float* __restrict__ mv, const int* __restrict__ table, float eps) {
+    const int* row = table + 8 * blockIdx.y;
+    const long off = row[0];
+    const int cout = row[1], ktot = row[2], bn = row[5], fb = row[6];
+    const long total = (long)cout * ktot;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int co = (int)(i / ktot);
+        const float s = bn >= 0 ? rsqrtf(mv[bn + co] + eps) : 1.f;
+        wf[off + i] = LP<T>::from_f32(w[off + i] * s);
+    }
+    if (bn >= 0 && fb >= 0 && blockIdx.x == 0)
+        for (int co = threadIdx.x; co < cout; co += 256) {
+            const float s = rsqrtf(mv[bn + co] + eps);
+            fold_bias[fb + co] = beta[bn + co] - mm[bn + co] * s;
+        }
+}
+
+}  // namespace fn
+using namespace fn;
+
+extern "C" int fn_adam_keras(float* w, const float* g, float* m, float* v, void* w_lp, long n_lp, long n, long n_decay, float* hyper, float beta1,
+                             float beta2, float eps, float l2, int dtype, void* stream) {
+    FN_REQUIRE(dtype == FN_BF16 || dtype == FN_F16, "dtype %d unsupported", dtype);
+    FN_REQUIRE(w && g && m && v && hyper && n > 0 && n % 4 == 0 && n_decay >= 0 && n_decay <= n && n_lp % 4 == 0 && n_lp <= n,
+               "adam_keras: bad arguments (n %% 4 == 0)");
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == FN_BF16)
+        hipLaunchKernelGGL(adam_keras_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (unsigned short*)w_lp, n_lp, n, n_decay, hyper, beta1, beta2, eps, l2);
+    else
+        hipLaunchKernelGGL(adam_keras_kernel<_Float16>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (unsigned short*)w_lp, n_lp, n, n_decay, hyper, beta1, beta2, eps, l2);
+    return check_launch("adam_keras");
+}
+
+extern "C" int fn_adam_tick(float* hyper, float beta1, float beta2, void* stream) {
+    FN_REQUIRE(hyper, "adam_tick: null hyper");
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper, beta1, beta2);
+    return check_launch("adam_tick");
+}
+
+extern "C" int fn_pack_transpose(const void* w_lp, void* wt_lp, const int32_t* table, int n_layers, int max_layer_elems, int dtype, void* stream) {
+    FN_REQUIRE(dtype == FN_BF16 || dtype == FN_F16, "dtype %d unsupported", dtype);
+    FN_REQUIRE(w_lp && wt_lp && table && n_layers > 0 && max_layer_elems > 0, "pack_transpose: bad arguments");
+    int gx = cdiv(max_layer_elems, 256 * 8);
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(pack_transpose_kernel<__bf16>, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)w_lp,
+                       (unsigned short*)wt_lp, table);  // pure 16-bit moves: one instantiation serves both dtypes
+    return check_launch("pack_transpose");
+}
+
+extern "C" int fn_fold_bn(const float* w, void* wf_lp, float* fold_bias, const float* beta, const float* moving_mean, const float* moving_var,
+                          const int32_t* table, int n_layers, int max_layer_elems, float eps, int dtype, void* stream) {
+    FN_REQUIRE(dtype == FN_BF16 || dtype == FN_F16, "dtype %d unsupported", dtype);
+    FN_REQUIRE(w && wf_lp && fold_bias && beta && moving_mean && moving_var && table && n_layers > 0, "fold_bn: bad arguments");
+    int gx = cdiv(max_layer_elems, 256 * 8);
+    if (gx > 256) gx = 256;
+    if (dtype == FN_BF16)
+        hipLaunchKernelGGL(fold_bn_kernel<__bf16>, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)wf_lp, fold_bias, beta, moving_mean, moving_var, table, eps);
+    else
+        hipLaunchKernelGGL(fold_bn_kernel<_Float16>, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)wf_lp, fold_bias, beta, moving_mean, moving_var, table, eps);
+    return check_launch("fold_bn");
+}

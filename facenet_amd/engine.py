@@ -1,0 +1,698 @@
+"""Static-plan execution engine for the Inception-ResNet-v1 hot path on MI355X.
+
+The reference runs this path through Keras/TensorFlow's graph runtime
+(facenet/models/inception_resnet_v1.py:380-494 built by ``self(input_shape)``, trained by
+``network.fit`` at apps/train_softmax.py:95-104).  Here the network is lowered ONCE, for a fixed
+batch size, into a flat list of C-ABI kernel launches over pre-allocated HBM buffers:
+
+  * every activation tensor lives for the whole step (288 GB of HBM: nothing is recomputed or
+    re-allocated); towers write straight into channel slices of their concat buffer;
+  * parameters, gradients and Adam state are single flat fp32 buffers (one fused optimiser launch,
+    contiguous all-reduce buckets); the MFMA kernels read low-precision packs of the same layout;
+  * the launch list is replayed eagerly or captured into one HIP graph (engine.GraphRunner) -
+    HIP streams and graphs instead of a tracing compiler;
+  * backward is derived here, op by op, in reverse order of the forward records (no autograd).
+
+PyTorch supplies device memory, streams and torch.distributed only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvDesc
+
+BN_EPS = 1e-3        # Keras default (inception_resnet_v1.py:57-58 commented out)
+BN_MOMENTUM = 0.99   # Keras default
+L2_WEIGHT = 5e-4     # inception_resnet_v1.py:65
+
+DEFAULT_CONFIG = {   # inception_resnet_v1.py:13-43
+    "reduction_a": {"filters": [[384], [192, 192, 256]]},
+    "reduction_b": {"filters": [[256, 384], [256, 256], [256, 256, 256]]},
+    "block35": {"repeat": 5, "scale": 0.17, "activation": "relu"},
+    "block17": {"repeat": 10, "scale": 0.10, "activation": "relu"},
+    "block8_1": {"repeat": 5, "scale": 0.2, "activation": "relu"},
+    "block8_2": {"scale": 1.0, "activation": None},
+    "output": {"size": 512},
+}
+
+
+def _pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+# ------------------------------------------------------------------------------------------------
+# declarations
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Layer:
+    name: str
+    cin: int          # padded to a multiple of 8
+    cin_real: int
+    cout: int
+    kh: int
+    kw: int
+    stride: int
+    pad_h: int
+    pad_w: int
+    has_bn: bool
+    has_bias: bool
+    dense: bool = False
+    cout_real: int = -1   # un-padded output channels (classifier only differs)
+    w_off: int = -1       # element offset of [cout][kh][kw][cin] in the flat parameter buffer
+    bias_off: int = -1    # element offset of the bias in the flat parameter buffer
+    bn_off: int = -1      # offset in the global BatchNorm channel space
+    index: int = -1
+
+    @property
+    def ktot(self) -> int:
+        return self.kh * self.kw * self.cin
+
+    @property
+    def numel(self) -> int:
+        return self.cout * self.ktot
+
+
+class Buf:
+    """One NHWC activation tensor: raw conv output, activated output and (training) gradient."""
+
+    def __init__(self, name: str, N: int, H: int, W: int, Cc: int, bn_off: Optional[int] = None):
+        self.name, self.N, self.H, self.W, self.C = name, N, H, W, Cc
+        self.bn_off = bn_off
+        self.act: Optional[torch.Tensor] = None
+        self.raw: Optional[torch.Tensor] = None
+        self.grad: Optional[torch.Tensor] = None
+        self.grad_ranges: List[Tuple[int, int]] = []
+        self.f32 = False
+
+    @property
+    def M(self) -> int:
+        return self.N * self.H * self.W
+
+    def full(self) -> "Slice":
+        return Slice(self, 0, self.C)
+
+    def sl(self, c0: int, c: int) -> "Slice":
+        return Slice(self, c0, c)
+
+
+@dataclass
+class Slice:
+    buf: Buf
+    c0: int
+    C: int
+
+
+@dataclass
+class Rec:
+    kind: str
+    layer: Optional[Layer] = None
+    x: Optional[Slice] = None
+    y: Optional[Slice] = None
+    extra: dict = field(default_factory=dict)
+
+
+@dataclass
+class Op:
+    name: str
+    fn: Callable
+    args: tuple
+    keep: tuple = ()
+
+
+def _ptr(t: torch.Tensor, elem_off: int = 0) -> int:
+    return t.data_ptr() + elem_off * t.element_size()
+
+
+# ------------------------------------------------------------------------------------------------
+# the network
+# ------------------------------------------------------------------------------------------------
+class Network:
+    """Parameters + topology of Inception-ResNet-v1; ``plan()`` lowers it for one batch size."""
+
+    def __init__(self, embedding_size: int = 512, config: Optional[dict] = None, image_size: int = 160,
+                 normalization: int = 0, nrof_classes: Optional[int] = None, device: str = "cuda",
+                 train_dtype: torch.dtype = torch.bfloat16, infer_dtype: torch.dtype = torch.float16, seed: int = 0):
+        self.cfg = {k: (dict(v) if isinstance(v, dict) else v) for k, v in DEFAULT_CONFIG.items()}
+        if config:
+            for k, v in config.items():
+                self.cfg[k] = v
+        self.E = int(embedding_size)
+        self.image_size = int(image_size)
+        self.normalization = int(normalization)
+        self.nrof_classes = nrof_classes
+        self.device = torch.device(device)
+        self.train_dtype, self.infer_dtype = train_dtype, infer_dtype
+        if self.device.type != "cuda":
+            raise _lib.FacenetHipError("facenet_amd runs on a HIP device only (no CPU fallback)")
+        self.lib = _lib.load()
+
+        self.layers: "OrderedDict[str, Layer]" = OrderedDict()
+        self.buf_bn: Dict[str, int] = {}     # buffer name -> BN channel offset
+        self.CB = 0                          # size of the global BN channel space
+        self._declare()
+        self._layout()
+        self._alloc_params(seed)
+
+    # ---- topology (written from inception_resnet_v1.py; independent of oracle/) ------------------
+    def _topology(self, g: "Lowering"):
+        cfg = self.cfg
+        s = self.image_size
+        x = g.input(s, s)
+        x = g.cbr("conv2d/Conv2d_1a_3x3", x, 32, (3, 3), 2, "valid", cin_real=3)       # :388
+        x = g.cbr("conv2d/Conv2d_2a_3x3", x, 32, (3, 3), 1, "valid")                   # :395
+        x = g.cbr("conv2d/Conv2d_2b_3x3", x, 64, (3, 3), 1, "valid")                   # :402 ('valid' in this fork)
+        x = g.maxpool("conv2d/MaxPool_3a_3x3", x)                                      # :409
+        x = g.cbr("conv2d/Conv2d_3b_1x1", x, 80, (1, 1), 1, "valid")                   # :410
+        x = g.cbr("conv2d/Conv2d_4a_3x3", x, 192, (3, 3), 1, "valid")                  # :417
+        x = g.cbr("conv2d/Conv2d_4b_3x3", x, 256, (3, 3), 2, "valid")                  # :424
+        b35 = [[("Conv2d_1x1", 32, (1, 1))],
+               [("Conv2d_0a_1x1", 32, (1, 1)), ("Conv2d_0b_3x3", 32, (3, 3))],
+               [("Conv2d_0a_1x1", 32, (1, 1)), ("Conv2d_0b_3x3", 32, (3, 3)), ("Conv2d_0c_3x3", 32, (3, 3))]]
+        for i in range(cfg["block35"]["repeat"]):                                      # :433-435 ; relu hard-coded :88
+            x = g.block(f"block35/{i}", x, b35, 256, cfg["block35"]["scale"], True)
+        fa = cfg["reduction_a"]["filters"]                                              # :262-307
+        x = g.reduction("reduction_a", x, [
+            [("Conv2d_1a_3x3", fa[0][0], (3, 3), 2, "valid")],
+            [("Conv2d_0a_1x1", fa[1][0], (1, 1), 1, "same"), ("Conv2d_0b_3x3", fa[1][1], (3, 3), 1, "same"),
+             ("Conv2d_1a_3x3", fa[1][2], (3, 3), 2, "valid")]])
+        b17 = [[("Conv2d_1x1", 128, (1, 1))],
+               [("Conv2d_0a_1x1", 128, (1, 1)), ("Conv2d_0b_1x7", 128, (1, 7)), ("Conv2d_0c_7x1", 128, (7, 1))]]
+        for i in range(cfg["block17"]["repeat"]):                                      # :441-443 ; relu hard-coded :158
+            x = g.block(f"block17/{i}", x, b17, 896, cfg["block17"]["scale"], True)
+        fb = cfg["reduction_b"]["filters"]                                              # :310-377
+        x = g.reduction("reduction_b", x, [
+            [("Conv2d_0a_1x1", fb[0][0], (1, 1), 1, "same"), ("Conv2d_1a_3x3", fb[0][1], (3, 3), 2, "valid")],
+            [("Conv2d_0a_1x1", fb[1][0], (1, 1), 1, "same"), ("Conv2d_1a_3x3", fb[1][1], (3, 3), 2, "valid")],
+            [("Conv2d_0a_1x1", fb[2][0], (1, 1), 1, "same"), ("Conv2d_0b_3x3", fb[2][1], (3, 3), 1, "same"),
+             ("Conv2d_1a_3x3", fb[2][2], (3, 3), 2, "valid")]])
+        b8 = [[("Conv2d_1x1", 192, (1, 1))],
+              [("Conv2d_0a_1x1", 192, (1, 1)), ("Conv2d_0b_1x3", 192, (1, 3)), ("Conv2d_0c_3x1", 192, (3, 1))]]
+        for i in range(cfg["block8_1"]["repeat"]):                                     # :449-451 ; activation from config :213
+            x = g.block(f"block8/{i}", x, b8, 1792, cfg["block8_1"]["scale"], bool(cfg["block8_1"]["activation"]))
+        x = g.block("block8_2", x, b8, 1792, cfg["block8_2"]["scale"], bool(cfg["block8_2"]["activation"]))  # :453
+        return g.head(x, self.E)                                                         # :459-468
+
+    def _declare(self):
+        g = Lowering(self, N=1, training=False, declare=True)
+        self._topology(g)
+        if self.nrof_classes is not None:   # apps/train_softmax.py:57-63
+            L = self._declare_layer("classifier/logits", self.E, self.E, _pad8(self.nrof_classes), 1, 1, 1, 0, 0, has_bn=False,
+                                    has_bias=True, dense=True)
+            L.cout_real = self.nrof_classes     # padded rows stay exactly zero (zero init, zero gradient)
+
+    def _declare_layer(self, name, cin, cin_real, cout, kh, kw, stride, pad_h, pad_w, has_bn, has_bias, dense=False) -> Layer:
+        if name in self.layers:
+            return self.layers[name]
+        L = Layer(name, cin, cin_real, cout, kh, kw, stride, pad_h, pad_w, has_bn, has_bias, dense, cout_real=cout, index=len(self.layers))
+        self.layers[name] = L
+        return L
+
+    def _layout(self):
+        off = 0
+        for L in self.layers.values():
+            L.w_off = off
+            off += L.numel
+            assert L.numel % 8 == 0
+        self.n_kernel = off
+        self.n_decay = (off + 3) // 4 * 4            # coupled-L2 region of the flat buffer
+        self.beta_base = self.n_decay
+        off = self.beta_base + self.CB
+        for L in self.layers.values():
+            if L.has_bias:
+                L.bias_off = off
+                off += L.cout
+        self.n_params = (off + 3) // 4 * 4
+        self.max_layer_elems = max(L.numel for L in self.layers.values())
+
+    def _alloc_params(self, seed: int):
+        dev = self.device
+        self.P = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.S_mean = torch.zeros(self.CB, dtype=torch.float32, device=dev)
+        self.S_var = torch.ones(self.CB, dtype=torch.float32, device=dev)
+        self.W_train = torch.zeros(self.n_kernel, dtype=self.train_dtype, device=dev)
+        self.Wt_train = torch.zeros(self.n_kernel, dtype=self.train_dtype, device=dev)
+        self.W_infer = torch.zeros(self.n_kernel, dtype=self.infer_dtype, device=dev)
+        self.fold_bias = torch.zeros(self.CB, dtype=torch.float32, device=dev)
+        tab = np.zeros((len(self.layers), 8), dtype=np.int32)
+        for i, L in enumerate(self.layers.values()):
+            tab[i] = [L.w_off, L.cout, L.ktot, L.kh * L.kw, L.cin, L.bn_off if L.has_bn else -1,
+                      L.bn_off if L.has_bn else -1, 0]
+        self.table = torch.from_numpy(tab).to(dev)
+        self.G = None  # gradient / optimiser state are created by the Trainer
+        self.load_keras_params(self.init_keras_params(seed))
+
+    # ---- Keras-layout import / export (HWIO kernels, [in,out] dense; apps/train_softmax.py:68-78) ----
+    def init_keras_params(self, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+        """Glorot-uniform kernels (inception_resnet_v1.py:66), zero biases / beta, moving stats (0, 1),
+        drawn in declaration order from torch.Generator(seed) on the CPU."""
+        gen = torch.Generator().manual_seed(seed)
+        out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        for L in self.layers.values():
+            if L.dense:
+                w = torch.empty(L.cin_real, L.cout_real)
+                lim = math.sqrt(6.0 / (L.cin_real + L.cout_real))
+            else:
+                w = torch.empty(L.kh, L.kw, L.cin_real, L.cout)
+                lim = math.sqrt(6.0 / (L.kh * L.kw * (L.cin_real + L.cout)))
+            w.uniform_(-lim, lim, generator=gen)
+            out[L.name + "/kernel"] = w
+            if L.has_bias:
+                out[L.name + "/bias"] = torch.zeros(L.cout_real)
+            if L.has_bn:
+                pre = self._bn_prefix(L)
+                out[pre + "/beta"] = torch.zeros(L.cout)
+                out[pre + "/moving_mean"] = torch.zeros(L.cout)
+                out[pre + "/moving_variance"] = torch.ones(L.cout)
+        return out
+
+    @staticmethod
+    def _bn_prefix(L: Layer) -> str:
+        return "features/bn" if L.name == "features/logits" else L.name + "/bn"
+
+    def load_keras_params(self, params: Dict[str, torch.Tensor]):
+        P = torch.zeros(self.n_params, dtype=torch.float32)
+        mean = torch.zeros(self.CB)
+        var = torch.ones(self.CB)
+        for L in self.layers.values():
+            w = torch.as_tensor(params[L.name + "/kernel"]).to(torch.float32)
+            if L.dense:
+                w = w.t().reshape(L.cout_real, 1, 1, L.cin_real)
+                if L.cout != L.cout_real:
+                    w = torch.cat([w, torch.zeros(L.cout - L.cout_real, 1, 1, L.cin_real)], 0)
+            else:
+                w = w.permute(3, 0, 1, 2)                      # HWIO -> O,H,W,I
+            if L.cin != L.cin_real:
+                w = torch.nn.functional.pad(w, (0, L.cin - L.cin_real))
+            P[L.w_off:L.w_off + L.numel] = w.reshape(-1)
+            if L.has_bias:
+                P[L.bias_off:L.bias_off + L.cout_real] = torch.as_tensor(params[L.name + "/bias"]).to(torch.float32)
+            if L.has_bn:
+                pre = self._bn_prefix(L)
+                P[self.beta_base + L.bn_off:self.beta_base + L.bn_off + L.cout] = torch.as_tensor(params[pre + "/beta"])
+                mean[L.bn_off:L.bn_off + L.cout] = torch.as_tensor(params[pre + "/moving_mean"])
+                var[L.bn_off:L.bn_off + L.cout] = torch.as_tensor(params[pre + "/moving_variance"])
+        self.P.copy_(P)
+        self.S_mean.copy_(mean)
+        self.S_var.copy_(var)
+        self.refresh_packs()
+
+    def export_keras_params(self) -> "OrderedDict[str, torch.Tensor]":
+        P = self.P.detach().cpu()
+        mean, var = self.S_mean.cpu(), self.S_var.cpu()
+        out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        for L in self.layers.values():
+            w = P[L.w_off:L.w_off + L.numel].reshape(L.cout, L.kh, L.kw, L.cin)[:L.cout_real, ..., :L.cin_real]
+            out[L.name + "/kernel"] = (w.reshape(L.cout_real, L.cin_real).t() if L.dense else w.permute(1, 2, 3, 0)).contiguous()
+            if L.has_bias:
+                out[L.name + "/bias"] = P[L.bias_off:L.bias_off + L.cout_real].clone()
+            if L.has_bn:
+                pre = self._bn_prefix(L)
+                out[pre + "/beta"] = P[self.beta_base + L.bn_off:self.beta_base + L.bn_off + L.cout].clone()
+                out[pre + "/moving_mean"] = mean[L.bn_off:L.bn_off + L.cout].clone()
+                out[pre + "/moving_variance"] = var[L.bn_off:L.bn_off + L.cout].clone()
+        return out
+
+    def export_keras_grads(self, G: torch.Tensor) -> Dict[str, torch.Tensor]:
+        Gc = G.detach().cpu()
+        out = {}
+        for L in self.layers.values():
+            w = Gc[L.w_off:L.w_off + L.numel].reshape(L.cout, L.kh, L.kw, L.cin)[:L.cout_real, ..., :L.cin_real]
+            out[L.name + "/kernel"] = (w.reshape(L.cout_real, L.cin_real).t() if L.dense else w.permute(1, 2, 3, 0)).contiguous()
+            if L.has_bias:
+                out[L.name + "/bias"] = Gc[L.bias_off:L.bias_off + L.cout_real].clone()
+            if L.has_bn:
+                out[self._bn_prefix(L) + "/beta"] = Gc[self.beta_base + L.bn_off:self.beta_base + L.bn_off + L.cout].clone()
+        return out
+
+    # ---- weight packs ---------------------------------------------------------------------------
+    def stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def refresh_packs(self, stream: Optional[int] = None):
+        """fp32 master -> training pack, transposed (dgrad) pack, BN-folded inference pack."""
+        st = self.stream() if stream is None else stream
+        self.W_train.copy_(self.P[:self.n_kernel])
+        self.refresh_transposed(st)
+        self.refresh_folded(st)
+
+    def refresh_transposed(self, st: int):
+        _lib.check(self.lib.fn_pack_transpose(_ptr(self.W_train), _ptr(self.Wt_train), _ptr(self.table), len(self.layers),
+                                              self.max_layer_elems, _lib.dtype_code(self.train_dtype), st), "pack_transpose")
+
+    def refresh_folded(self, st: int):
+        _lib.check(self.lib.fn_fold_bn(_ptr(self.P), _ptr(self.W_infer), _ptr(self.fold_bias), _ptr(self.P, self.beta_base),
+                                       _ptr(self.S_mean), _ptr(self.S_var), _ptr(self.table), len(self.layers),
+                                       self.max_layer_elems, BN_EPS, _lib.dtype_code(self.infer_dtype), st), "fold_bn")
+
+    def count_variables(self) -> Tuple[int, int]:
+        """(total, trainable) counted on the UN-padded Keras shapes (SURVEY.md shape table)."""
+        tot = tr = 0
+        for L in self.layers.values():
+            k = L.cout_real * L.kh * L.kw * L.cin_real
+            tr += k + (L.cout_real if L.has_bias else 0) + (L.cout if L.has_bn else 0)
+            tot += k + (L.cout_real if L.has_bias else 0) + (3 * L.cout if L.has_bn else 0)
+        return tot, tr
+
+    def plan(self, N: int, training: bool, loss: Optional[str] = None) -> "Lowering":
+        g = Lowering(self, N=N, training=training, declare=False, loss=loss)
+        g.embedding = self._topology(g)
+        g.finish()
+        return g
+
+
+# ------------------------------------------------------------------------------------------------
+# lowering: topology -> buffers + forward records -> launch lists
+# ------------------------------------------------------------------------------------------------
+class Lowering:
+    def __init__(self, net: Network, N: int, training: bool, declare: bool, loss: Optional[str] = None):
+        self.net, self.N, self.training, self.declare, self.loss = net, N, training, declare, loss
+        self.dtype = net.train_dtype if training else net.infer_dtype
+        self.dt = None if declare else _lib.dtype_code(self.dtype)
+        self.bufs: "OrderedDict[str, Buf]" = OrderedDict()
+        self.recs: List[Rec] = []
+        self.fwd: List[Op] = []
+        self.bwd: List[Op] = []
+        self.bwd_marks: List[Tuple[int, int]] = []   # (index into bwd after which..., lowest finished w_off)
+        self.embedding = None
+
+    # ---- buffers -------------------------------------------------------------------------------
+    def buf(self, name: str, H: int, W: int, Cc: int, bn_channels: int = 0, need_raw: bool = False, f32: bool = False) -> Buf:
+        net = self.net
+        if self.declare:
+            bn_off = None
+            if bn_channels:
+                bn_off = net.CB
+                net.buf_bn[name] = bn_off
+                net.CB += bn_channels
+            b = Buf(name, self.N, H, W, Cc, bn_off)
+        else:
+            b = Buf(name, self.N, H, W, Cc, net.buf_bn.get(name))
+            dt = torch.float32 if f32 else self.dtype
+            b.f32 = f32
+            b.act = torch.zeros(self.N, H, W, Cc, dtype=dt, device=net.device)
+            if self.training:
+                if need_raw:
+                    b.raw = torch.zeros(self.N, H, W, Cc, dtype=dt, device=net.device)
+                b.grad = torch.zeros(self.N, H, W, Cc, dtype=dt, device=net.device)
+        self.bufs[name] = b
+        return b
+
+    def input(self, H: int, W: int) -> Slice:
+        self.images = None if self.declare else torch.zeros(self.N, H, W, 3, dtype=torch.uint8, device=self.net.device)
+        self.norm_work = None if self.declare else torch.zeros(4 * self.N, dtype=torch.float32, device=self.net.device)
+        b = self.buf("input", H, W, 8)
+        return b.full()
+
+    @staticmethod
+    def _geom(H, W, k, stride, padding):
+        kh, kw = k
+        ph, pw = ((kh // 2, kw // 2) if padding == "same" else (0, 0))
+        if padding == "same":
+            assert stride == 1   # hazard 1: SAME only with stride 1 in v1
+        return kh, kw, ph, pw, (H + 2 * ph - kh) // stride + 1, (W + 2 * pw - kw) // stride + 1
+
+    def conv(self, name: str, x: Slice, cout: int, k, stride: int, padding: str, out: Optional[Slice] = None, has_bn=True,
+             has_bias=False, cin_real: Optional[int] = None, kind: str = "bn", **extra) -> Slice:
+        kh, kw, ph, pw, OH, OW = self._geom(x.buf.H, x.buf.W, k, stride, padding)
+        L = self.net._declare_layer(name, x.C, cin_real or x.C, cout, kh, kw, stride, ph, pw, has_bn, has_bias) \
+            if self.declare else self.net.layers[name]
+        if out is None:
+            ob = self.buf(name, OH, OW, cout, bn_channels=cout if has_bn else 0, need_raw=has_bn)
+            out = ob.full()
+        if self.declare and has_bn:
+            L.bn_off = out.buf.bn_off + out.c0
+        assert out.buf.H == OH and out.buf.W == OW and out.C == cout, name
+        self.recs.append(Rec("conv", L, x, out, dict(kind=kind, **extra)))
+        return out
+
+    def bn_apply(self, b: Buf, c0: int, Cc: int, relu: bool = True):
+        self.recs.append(Rec("bn", None, None, Slice(b, c0, Cc), dict(relu=relu)))
+
+    def cbr(self, name, x, cout, k, stride, padding, cin_real=None) -> Slice:
+        y = self.conv(name, x, cout, k, stride, padding, cin_real=cin_real)
+        self.bn_apply(y.buf, 0, cout)
+        return y
+
+    def maxpool(self, name: str, x: Slice, out: Optional[Slice] = None) -> Slice:
+        OH, OW = (x.buf.H - 3) // 2 + 1, (x.buf.W - 3) // 2 + 1
+        if out is None:
+            out = self.buf(name, OH, OW, x.C).full()
+        self.recs.append(Rec("maxpool", None, x, out))
+        return out
+
+    def _tower(self, prefix: str, x: Slice, tower, last_out: Slice) -> None:
+        for j, spec in enumerate(tower):
+            nm, cout, k = spec[0], spec[1], spec[2]
+            stride = spec[3] if len(spec) > 3 else 1
+            padding = spec[4] if len(spec) > 4 else "same"
+            name = f"{prefix}/{nm}"
+            if j == len(tower) - 1:
+                self.conv(name, x, cout, k, stride, padding, out=last_out)
+            else:
+                x = self.cbr(name, x, cout, k, stride, padding)
+
+    def block(self, prefix: str, trunk: Slice, towers, up: int, scale: float, relu: bool) -> Slice:
+        """Block35/17/8 (:83-259): towers -> concat -> up 1x1 (+bias) -> act(trunk + scale*up)."""
+        H, W = trunk.buf.H, trunk.buf.W
+        cm = sum(t[-1][1] for t in towers)
+        mixed = self.buf(prefix + "/mixed", H, W, cm, bn_channels=cm, need_raw=True)
+        c0 = 0
+        for i, t in enumerate(towers):
+            self._tower(f"{prefix}/tower_conv{i}", trunk, t, mixed.sl(c0, t[-1][1]))
+            c0 += t[-1][1]
+        self.bn_apply(mixed, 0, cm)                      # one pass over the whole concat buffer
+        out = self.buf(prefix + "/out", H, W, up)
+        self.conv(prefix + "/up", mixed.full(), up, (1, 1), 1, "same", out=out.full(), has_bn=False, has_bias=True,
+                  kind="resid", trunk=trunk, scale=float(scale), relu=bool(relu))
+        return out.full()
+
+    def reduction(self, prefix: str, trunk: Slice, towers) -> Slice:
+        """ReductionA/B (:262-377): strided towers + MaxPool, concatenated."""
+        H, W = trunk.buf.H, trunk.buf.W
+        OH, OW = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+        cbn = sum(t[-1][1] for t in towers)
+        out = self.buf(prefix + "/out", OH, OW, cbn + trunk.C, bn_channels=cbn, need_raw=True)
+        c0 = 0
+        for i, t in enumerate(towers):
+            self._tower(f"{prefix}/tower_conv{i}", trunk, t, out.sl(c0, t[-1][1]))
+            c0 += t[-1][1]
+        self.bn_apply(out, 0, cbn)
+        self.maxpool(prefix + "/MaxPool_1a_3x3", trunk, out=out.sl(cbn, trunk.C))
+        return out.full()
+
+    def head(self, x: Slice, E: int) -> Slice:
+        """features (:459-468): AvgPool2D([3,3]) valid (stride = pool) -> Flatten -> Dense(no bias) -> BN."""
+        H, W = x.buf.H, x.buf.W
+        if (H // 3, W // 3) != (1, 1):
+            raise ValueError(f"head expects a 3x3..5x5 final map (image size 160), got {H}x{W}")  # Flatten ambiguity, hazard 11
+        pooled = self.buf("features/avgpool", 1, 1, x.C)
+        self.recs.append(Rec("avgpool", None, x, pooled.full()))
+        yh = self.buf("features/logits", 1, 1, E, bn_channels=E, f32=True)
+        L = self.net._declare_layer("features/logits", x.C, x.C, E, 1, 1, 1, 0, 0, True, False, dense=True) \
+            if self.declare else self.net.layers["features/logits"]
+        if self.declare:
+            L.bn_off = yh.bn_off
+        self.recs.append(Rec("conv", L, pooled.full(), yh.full(), dict(kind="f32")))
+        emb = self.buf("features/bn", 1, 1, E, f32=True)
+        self.recs.append(Rec("head_bn", L, yh.full(), emb.full()))
+        return emb.full()
+
+    # ---- emission ------------------------------------------------------------------------------
+    def _desc(self, L: Layer, x: Slice, y: Slice) -> ConvDesc:
+        d = ConvDesc()
+        d.N, d.H, d.W, d.Cin = self.N, x.buf.H, x.buf.W, L.cin
+        d.OH, d.OW, d.Cout = y.buf.H, y.buf.W, L.cout
+        d.KH, d.KW, d.stride, d.pad_h, d.pad_w = L.kh, L.kw, L.stride, L.pad_h, L.pad_w
+        d.dtype = self.dt
+        d.ld_x, d.ld_y = x.buf.C, y.buf.C
+        d.scale = 1.0
+        return d
+
+    def _emit(self, lst: List[Op], name: str, fn, *args, keep=()):
+        lst.append(Op(name, fn, args, tuple(keep)))
+
+    def _grad_mode(self, s: Slice) -> int:
+        """0 = first writer of this channel range (overwrite), 1 = accumulate."""
+        rng = (s.c0, s.c0 + s.C)
+        for (a, b) in s.buf.grad_ranges:
+            if a <= rng[0] and rng[1] <= b:
+                return 1
+        s.buf.grad_ranges.append(rng)
+        return 0
+
+    def finish(self):
+        net, lib = self.net, self.net.lib
+        dev = net.device
+        CB = net.CB
+        N = self.N
+        if self.training:
+            self.ws = torch.zeros(3 * CB, dtype=torch.float32, device=dev)      # sum | sumsq | s2
+            self.save_scale = torch.zeros(CB, dtype=torch.float32, device=dev)
+            self.save_shift = torch.zeros(CB, dtype=torch.float32, device=dev)
+            self.head_mean = torch.zeros(net.E, dtype=torch.float32, device=dev)
+            self.head_rstd = torch.zeros(net.E, dtype=torch.float32, device=dev)
+        f = self.fwd
+        self._emit(f, "image_normalize", lib.fn_image_normalize, _ptr(self.images), _ptr(self.bufs["input"].act), _ptr(self.norm_work),
+                   N, self.images.shape[1] * self.images.shape[2], net.normalization, self.dt)
+        for r in self.recs:
+            getattr(self, "_fwd_" + r.kind)(r)
+
+    # forward emitters
+    def _fwd_conv(self, r: Rec):
+        net, lib, L = self.net, self.net.lib, r.layer
+        kind = r.extra["kind"]
+        d = self._desc(L, r.x, r.y)
+        d.x = _ptr(r.x.buf.act, r.x.c0)
+        if self.training:
+            d.w = _ptr(net.W_train, L.w_off)
+            if kind == "bn":
+                d.y = _ptr(r.y.buf.raw, r.y.c0)
+                d.stats = _ptr(self.ws, L.bn_off)
+                d.stats_sq_off = net.CB
+        else:
+            d.w = _ptr(net.W_infer, L.w_off)
+            if kind == "bn":
+                d.y = _ptr(r.y.buf.act, r.y.c0)
+                d.bias = _ptr(net.fold_bias, L.bn_off)
+                d.relu = 1
+        if kind == "resid":
+            t: Slice = r.extra["trunk"]
+            d.y = _ptr(r.y.buf.act, r.y.c0)
+            d.bias = _ptr(net.P, L.bias_off)
+            d.resid = _ptr(t.buf.act, t.c0)
+            d.ld_res = t.buf.C
+            d.scale = r.extra["scale"]
+            d.relu = 1 if r.extra["relu"] else 0
+        elif kind == "f32":
+            tgt = r.y.buf
+            if L.has_bn and not self.training:       # inference: BN folded, write the embedding buffer directly
+                tgt = self.bufs["features/bn"]
+                d.bias = _ptr(net.fold_bias, L.bn_off)
+            d.y = _ptr(tgt.act, r.y.c0)
+            d.out_f32 = 1
+            if L.has_bias:
+                d.bias = _ptr(net.P, L.bias_off)
+        self._emit(self.fwd, "conv_fwd:" + L.name, lib.fn_conv2d_fwd, C.byref(d), keep=(d,))
+
+    def _fwd_bn(self, r: Rec):
+        if not self.training:
+            return  # folded into the convolution epilogue (facenet/tfutils.py:244-250)
+        net, lib = self.net, self.net.lib
+        b, c0, Cc = r.y.buf, r.y.c0, r.y.C
+        o = b.bn_off + c0
+        self._emit(self.fwd, "bn_relu_fwd:" + b.name, lib.fn_bn_relu_train_fwd, _ptr(b.raw, c0), b.C, _ptr(b.act, c0), b.C, b.M, Cc,
+                   _ptr(self.ws, o), net.CB, _ptr(net.P, net.beta_base + o), _ptr(self.save_scale, o), _ptr(self.save_shift, o),
+                   _ptr(net.S_mean, o), _ptr(net.S_var, o), BN_MOMENTUM, BN_EPS, 1 if r.extra["relu"] else 0, self.dt)
+
+    def _fwd_maxpool(self, r: Rec):
+        x, y = r.x, r.y
+        self._emit(self.fwd, "maxpool_fwd", self.net.lib.fn_maxpool3x3s2_fwd, _ptr(x.buf.act, x.c0), x.buf.C, _ptr(y.buf.act, y.c0), y.buf.C,
+                   self.N, x.buf.H, x.buf.W, x.C, self.dt)
+
+    def _fwd_avgpool(self, r: Rec):
+        x, y = r.x, r.y
+        self._emit(self.fwd, "avgpool_fwd", self.net.lib.fn_avgpool_fwd, _ptr(x.buf.act), _ptr(y.buf.act), self.N, x.buf.H * x.buf.W, x.C, self.dt)
+
+    def _fwd_head_bn(self, r: Rec):
+        if not self.training:
+            return  # folded into the Dense epilogue
+        net, L = self.net, r.layer
+        o = L.bn_off
+        tr = 1 if self.training else 0
+        sm = _ptr(self.head_mean) if self.training else None
+        sr = _ptr(self.head_rstd) if self.training else None
+        self._emit(self.fwd, "head_bn_fwd", net.lib.fn_head_bn_fwd, _ptr(r.x.buf.act), _ptr(r.y.buf.act), self.N, net.E,
+                   _ptr(net.P, net.beta_base + o), _ptr(net.S_mean, o), _ptr(net.S_var, o), sm, sr, tr, BN_MOMENTUM, BN_EPS)
+
+    # ---- backward (training plans only); demb = fp32 gradient wrt the un-normalised embedding ----
+    def build_backward(self, demb: torch.Tensor):
+        assert self.training and not self.bwd
+        for b in self.bufs.values():
+            b.grad_ranges = []
+        self._demb = demb
+        for r in reversed(self.recs):
+            getattr(self, "_bwd_" + r.kind)(r)
+
+    def _mark(self, L: Layer):
+        self.bwd_marks.append((len(self.bwd), L.index))
+
+    def _bwd_head_bn(self, r: Rec):
+        net, L = self.net, r.layer
+        # dy (low precision) lands in the grad buffer of the fp32 logits buffer's low-precision shadow
+        self.head_dy = torch.zeros(self.N, net.E, dtype=self.dtype, device=net.device)
+        self._emit(self.bwd, "head_bn_bwd", net.lib.fn_head_bn_bwd, _ptr(self._demb), _ptr(r.x.buf.act), _ptr(self.head_mean),
+                   _ptr(self.head_rstd), _ptr(net.G, net.beta_base + L.bn_off), _ptr(self.head_dy), self.N, net.E, self.dt)
+
+    def _bwd_conv(self, r: Rec):
+        net, lib, L = self.net, self.net.lib, r.layer
+        kind = r.extra["kind"]
+        x, y = r.x, r.y
+        if kind == "resid":
+            t: Slice = r.extra["trunk"]
+            if not hasattr(self, "_dup") or self._dup.get((y.buf.M, y.buf.C)) is None:
+                self._dup = getattr(self, "_dup", {})
+                self._dup[(y.buf.M, y.buf.C)] = torch.zeros(y.buf.M, y.buf.C, dtype=self.dtype, device=net.device)
+            dup = self._dup[(y.buf.M, y.buf.C)]
+            acc = self._grad_mode(t)
+            self._emit(self.bwd, "residual_bwd:" + L.name, lib.fn_residual_bwd, _ptr(y.buf.grad), _ptr(y.buf.act), _ptr(t.buf.grad),
+                       _ptr(dup), _ptr(net.G, L.bias_off), y.buf.M, y.buf.C, r.extra["scale"], 1 if r.extra["relu"] else 0, acc, self.dt)
+            dy_ptr, ld_dy = _ptr(dup), y.buf.C
+        elif kind == "f32":
+            dy_ptr, ld_dy = _ptr(self.head_dy), net.E
+        else:
+            dy_ptr, ld_dy = _ptr(y.buf.grad, y.c0), y.buf.C
+        d = self._desc(L, x, y)
+        d.ld_y = ld_dy
+        d.x = _ptr(x.buf.act, x.c0)
+        d.y = dy_ptr
+        d.dw = _ptr(net.G, L.w_off)
+        self._emit(self.bwd, "conv_wgrad:" + L.name, lib.fn_conv2d_wgrad, C.byref(d), keep=(d,))
+        if x.buf.name != "input":
+            g = self._desc(L, x, y)
+            g.ld_y = ld_dy
+            g.y = dy_ptr
+            g.w = _ptr(net.Wt_train, L.w_off)
+            g.dx = _ptr(x.buf.grad, x.c0)
+            g.accumulate = self._grad_mode(x)
+            self._emit(self.bwd, "conv_dgrad:" + L.name, lib.fn_conv2d_dgrad, C.byref(g), keep=(g,))
+        self._mark(L)
+
+    def _bwd_bn(self, r: Rec):
+        net = self.net
+        b, c0, Cc = r.y.buf, r.y.c0, r.y.C
+        o = b.bn_off + c0
+        self._emit(self.bwd, "bn_relu_bwd:" + b.name, net.lib.fn_bn_relu_train_bwd, _ptr(b.grad, c0), b.C, _ptr(b.raw, c0), b.C, b.M, Cc,
+                   _ptr(net.P, net.beta_base + o), _ptr(self.save_scale, o), _ptr(self.save_shift, o), _ptr(net.G, net.beta_base + o),
+                   _ptr(self.ws, 2 * net.CB + o), 1 if r.extra["relu"] else 0, self.dt)
+
+    def _bwd_maxpool(self, r: Rec):
+        x, y = r.x, r.y
+        if x.buf.name == "input":
+            return
+        acc = self._grad_mode(x)
+        self._emit(self.bwd, "maxpool_bwd", self.net.lib.fn_maxpool3x3s2_bwd, _ptr(x.buf.act, x.c0), x.buf.C, _ptr(y.buf.grad, y.c0), y.buf.C,
+                   _ptr(x.buf.grad, x.c0), x.buf.C, self.N, x.buf.H, x.buf.W, x.C, acc, self.dt)
+
+    def _bwd_avgpool(self, r: Rec):
+        x, y = r.x, r.y
+        assert self._grad_mode(x) == 0
+        self._emit(self.bwd, "avgpool_bwd", self.net.lib.fn_avgpool_bwd, _ptr(y.buf.grad), _ptr(x.buf.grad), self.N, x.buf.H * x.buf.W, x.C, self.dt)
+
+    # ---- execution -----------------------------------------------------------------------------
+    @staticmethod
+    def run_ops(ops: Sequence[Op], stream: int, lo: int = 0, hi: Optional[int] = None):
+        for op in ops[lo:hi]:
+            rc = op.fn(*op.args, stream)
+            if rc:
+                _lib.check(rc, op.name)
+
+    def run_forward(self, stream: Optional[int] = None):
+        self.run_ops(self.fwd, self.net.stream() if stream is None else stream)

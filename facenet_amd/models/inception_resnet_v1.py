@@ -1,0 +1,96 @@
+"""``InceptionResnetV1`` with the reference's call contract (facenet/models/inception_resnet_v1.py:380-501):
+``InceptionResnetV1(input_shape, image_processing, config=None)``; ``model(inputs, training=False) -> float32 [N,E]``
+(L2-normalised when ``training`` is False, :491-492); ``.config``, ``.image_processing``, ``.custom_layers``, ``.summary()``.
+Every launch is a hand-written gfx950 kernel behind libfacenet_hip.so; plans are cached per batch size."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..config import Config
+from ..engine import DEFAULT_CONFIG, Lowering, Network, _ptr
+
+default_config = DEFAULT_CONFIG
+
+
+def check_input_config(cfg=None):
+    return Config(default_config) if cfg is None else cfg
+
+
+class InceptionResnetV1:
+    def __init__(self, input_shape, image_processing, config=None, device: str = "cuda", seed: int = 0,
+                 infer_dtype: torch.dtype = torch.float16, train_dtype: torch.dtype = torch.bfloat16, nrof_classes=None):
+        self.config = check_input_config(config)
+        self.image_processing = image_processing
+        cfg = self.config.as_dict
+        size = int(input_shape[0]) if input_shape is not None else image_processing.config.size
+        norm = image_processing.config.normalization if image_processing is not None else 0
+        self.network = Network(embedding_size=cfg["output"]["size"], config=cfg, image_size=size, normalization=int(norm),
+                               nrof_classes=nrof_classes, device=device, train_dtype=train_dtype, infer_dtype=infer_dtype, seed=seed)
+        self.custom_layers = ("image_processing", "conv2d", "block35", "reduction_a", "block17", "reduction_b", "block8",
+                              "block8_2", "features")          # :470-480
+        self._plans: Dict[tuple, Lowering] = {}
+        self._f32_in: Dict[int, torch.Tensor] = {}
+
+    @property
+    def embedding_size(self) -> int:
+        return self.network.E
+
+    def _plan(self, n: int, training: bool) -> Lowering:
+        key = (n, training)
+        if key not in self._plans:
+            self._plans[key] = self.network.plan(n, training=training)
+        return self._plans[key]
+
+    def __call__(self, inputs, training: bool = False, **kwargs) -> torch.Tensor:
+        net = self.network
+        x = torch.as_tensor(np.asarray(inputs)) if not torch.is_tensor(inputs) else inputs
+        if x.dim() != 4 or x.shape[3] != 3:
+            raise ValueError(f"expected NHWC images [N,{net.image_size},{net.image_size},3], got {tuple(x.shape)}")
+        if x.shape[1] != net.image_size or x.shape[2] != net.image_size:
+            raise ValueError("tf.image.resize (facenet.py:70) is the identity at the configured size; other sizes are not supported")
+        n = x.shape[0]
+        plan = self._plan(n, training)
+        st = net.stream()
+        if not training:
+            net.refresh_folded(st)
+        if x.dtype == torch.uint8:
+            plan.images.copy_(x.to(net.device))
+            Lowering.run_ops(plan.fwd, st)
+        else:   # float images: facenet.py:69 casts to float32 anyway
+            xf = x.to(device=net.device, dtype=torch.float32).contiguous()
+            _lib.check(net.lib.fn_image_normalize_f32(_ptr(xf), _ptr(plan.bufs["input"].act), _ptr(plan.norm_work), n,
+                                                      net.image_size * net.image_size, net.normalization, plan.dt, st), "image_normalize")
+            Lowering.run_ops(plan.fwd[1:], st)
+        emb = plan.embedding.buf.act.view(n, net.E)
+        if training:
+            return emb.clone()                 # un-normalised in training (:491)
+        out = torch.empty_like(emb)
+        _lib.check(net.lib.fn_l2norm_fwd(_ptr(emb), _ptr(out), n, net.E, 1e-10, st), "l2norm")   # :492
+        return out
+
+    def summary(self, line_length=None, positions=None, print_fn=None):
+        pr = print_fn or print
+        for L in self.network.layers.values():
+            pr(f"{L.name:60s} {L.kh}x{L.kw}/s{L.stride} {L.cin_real:5d} -> {L.cout_real:5d}" + ("  +BN" if L.has_bn else "") + ("  +bias" if L.has_bias else ""))
+        tot, tr = self.network.count_variables()
+        pr(f"Total variables: {tot}")
+        pr(f"Trainable variables: {tr}")
+        pr(f"Non-trainable variables: {tot - tr}")
+
+    # weights in Keras layout (HWIO / [in,out]); apps/train_softmax.py:68-78 load_weights / ModelCheckpoint
+    def get_weights(self):
+        return self.network.export_keras_params()
+
+    def set_weights(self, params):
+        self.network.load_keras_params(params)
+
+    def save_weights(self, path):
+        np.savez(path, **{k: v.numpy() for k, v in self.network.export_keras_params().items()})
+
+    def load_weights(self, path):
+        with np.load(path, allow_pickle=False) as z:
+            self.network.load_keras_params({k: torch.from_numpy(z[k]) for k in z.files})

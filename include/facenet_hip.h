@@ -1,0 +1,138 @@
+/* C ABI of libfacenet_hip.so -- the MI355X (gfx950) drop-in boundary for the
+ * sMedX/FaceNet training/inference hot path.
+ *
+ * The reference has no FFI of its own: its hot path is the set of TensorFlow /
+ * Keras ops called from facenet/models/inception_resnet_v1.py, facenet/facenet.py,
+ * facenet/statistics.py and apps/train_softmax.py.  Every entry point below
+ * cites the reference call site(s) whose arithmetic it replaces.
+ *
+ * Conventions: plain pointers and sizes only; every pointer is DEVICE memory
+ * owned by the caller (activations NHWC, low precision = bf16 or f16 selected
+ * by `dtype`; parameters/gradients fp32); kernels never allocate; every call
+ * is asynchronous on `stream` (a hipStream_t) and is HIP-graph capturable;
+ * return 0 on success, negative on error with text in fn_last_error()
+ * (thread-local).  No global mutable state: calls are re-entrant.
+ */
+#ifndef FACENET_HIP_H
+#define FACENET_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FN_BF16 0
+#define FN_F16 1
+
+const char* fn_last_error(void);
+int fn_abi_version(void);
+
+/* ---- convolution as implicit GEMM on MFMA ------------------------------------
+ * Replaces tf.keras.layers.Conv2D (+ the BatchNormalization statistics pass, ReLU,
+ * bias, tf.concat and the residual "net += scale * up" that surround it):
+ * inception_resnet_v1.py:90-138,160-193,215-248,269-299,316-367,387-430 (Conv2D),
+ * :141-148,196-202,251-257 (concat + residual), :304-306,372-375 (concat),
+ * and the Dense layers at :462 and apps/train_softmax.py:57-63 (a 1x1 conv on [N,1,1,C]).
+ * The descriptor always states the FORWARD geometry of the layer. */
+typedef struct fn_conv_desc {
+    int32_t N, H, W, Cin;      /* forward input  [N,H,W,Cin]  */
+    int32_t OH, OW, Cout;      /* forward output [N,OH,OW,Cout] */
+    int32_t KH, KW, stride, pad_h, pad_w;
+    int32_t dtype;             /* FN_BF16 | FN_F16 : activation + packed-weight storage */
+    int32_t ld_x, ld_y;        /* channel stride (elements) of the x-side and y-side buffers (concat-free slices) */
+    int32_t relu;              /* fwd epilogue: max(.,0) */
+    int32_t accumulate;        /* fwd/dgrad epilogue: add to what `y`/`dx` already holds */
+    int32_t out_f32;           /* fwd: y (dgrad: dx) is fp32 instead of low precision */
+    int32_t ld_res;            /* channel stride of resid */
+    float scale;               /* fwd: y = resid + scale*(conv + bias) when resid != NULL, else conv + bias */
+    int32_t splits;            /* wgrad: split-K factor over pixels (0 = library picks) */
+    int32_t stats_sq_off;      /* fwd: element offset from the sum array to the sum-of-squares array in `stats` */
+    const void* x;             /* fwd/wgrad: input activations; dgrad: unused */
+    const void* w;             /* fwd: packed [Cout][KH*KW*Cin]; dgrad: transposed pack [Cin][KH*KW*Cout] */
+    void* y;                   /* fwd: output; dgrad/wgrad: dY (read) */
+    void* dx;                  /* dgrad: output dX [N,H,W,ld_x] */
+    float* dw;                 /* wgrad: fp32 [Cout][KH*KW*Cin], atomically accumulated (caller zeroes) */
+    const float* bias;         /* fwd: per-Cout fp32 or NULL (BN-folded shift / `up` bias) */
+    float* stats;              /* fwd: NULL or fp32: stats[c] += sum, stats[stats_sq_off + c] += sum of squares (BN batch statistics) */
+    const void* resid;         /* fwd: residual trunk [N,OH,OW,ld_res] or NULL */
+} fn_conv_desc;
+
+int fn_conv2d_fwd(const fn_conv_desc* d, void* stream);
+int fn_conv2d_dgrad(const fn_conv_desc* d, void* stream);
+int fn_conv2d_wgrad(const fn_conv_desc* d, void* stream);
+
+/* ---- input normalisation: facenet/facenet.py:67-86 (ImageProcessing.call) -------
+ * u8 NHWC [N,H,W,3] -> low precision [N,H,W,8] (channels 3..7 zero), mode 0 = per-image
+ * min/max to [-1,1], mode 1 = per_image_standardization.  `work` = fp32 [4*N] scratch. */
+int fn_image_normalize(const uint8_t* img, void* out, float* work, int N, int HW, int mode, int dtype, void* stream);
+int fn_image_normalize_f32(const float* img, void* out, float* work, int N, int HW, int mode, int dtype, void* stream);
+/* gather rows of a u8 image pool by index (triplet batch assembly): out[i] = pool[idx[i]] */
+int fn_gather_images(const uint8_t* pool, const int32_t* idx, uint8_t* out, int n_out, int bytes_per_image, void* stream);
+
+/* ---- BatchNormalization (center only, no scale; eps 1e-3, momentum 0.99) --------
+ * inception_resnet_v1.py:56-63 and every BatchNormalization(**...) line; ReLU() fused.
+ * Training: y (raw conv output, channel slice [0,C) of a [M,ld_y] buffer) -> z = relu((y-mean)*rstd+beta)
+ * with batch statistics from `stats` (sum,sumsq as written by fn_conv2d_fwd); scale=rstd and
+ * shift=beta-mean*rstd are saved for backward and the moving statistics are updated (biased variance). */
+int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, int M, int C, const float* stats, int stats_sq_off, const float* beta,
+                         float* save_scale, float* save_shift, float* moving_mean, float* moving_var, float momentum, float eps,
+                         int relu, int dtype, void* stream);
+/* backward: dz (grad wrt the BN+ReLU output) -> dy (grad wrt the raw conv output y), in place; y is the raw forward
+ * conv output (xhat and the ReLU mask are recomputed from it: masked elements still receive the batch-statistic
+ * terms).  dbeta[C] (+=) and s2[C] (+=, scratch zeroed by caller) are accumulated by the reduce kernel. */
+int fn_bn_relu_train_bwd(void* dz, int ld_d, const void* y, int ld_y, int M, int C, const float* beta, const float* save_scale,
+                         const float* save_shift, float* dbeta, float* s2, int relu, int dtype, void* stream);
+
+/* ---- pooling: MaxPool2D(3, strides=2, 'valid') :301,369,409 ; AvgPool2D([3,3]) + Flatten :460-461 */
+int fn_maxpool3x3s2_fwd(const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, int dtype, void* stream);
+int fn_maxpool3x3s2_bwd(const void* x, int ld_x, const void* dy, int ld_dy, void* dx, int ld_dx, int N, int H, int W, int C,
+                        int accumulate, int dtype, void* stream);
+int fn_avgpool_fwd(const void* x, void* y, int N, int HW, int C, int dtype, void* stream);
+int fn_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype, void* stream);
+
+/* ---- residual backward for "net = act(net + scale*up)" (:145-148,199-202,254-257) ------------
+ * dpre = dout * (out>0 if relu); dtrunk = dpre (or += when accumulate); dup = scale*dpre; dbias[C] += sum(dup). */
+int fn_residual_bwd(const void* dout, const void* out, void* dtrunk, void* dup, float* dbias, int M, int C, float scale, int relu,
+                    int accumulate, int dtype, void* stream);
+
+/* ---- embedding head on fp32 [N,E]: BN without ReLU (:467) and tf.nn.l2_normalize (:491-492) ---- */
+int fn_head_bn_fwd(const float* y, float* out, int N, int E, const float* beta, float* moving_mean, float* moving_var,
+                   float* save_mean, float* save_rstd, int training, float momentum, float eps, void* stream);
+int fn_head_bn_bwd(const float* dout, const float* y, const float* save_mean, const float* save_rstd, float* dbeta, void* dy_lp,
+                   int N, int E, int dtype, void* stream);
+int fn_l2norm_fwd(const float* x, float* out, int N, int E, float eps, void* stream);
+int fn_l2norm_bwd(const float* x, const float* dout, float* dx, int N, int E, float eps, void* stream);
+int fn_cast_f32_to_lp(const float* x, void* y, long n, int dtype, void* stream);
+
+/* ---- distances / triplets ---------------------------------------------------------------------
+ * fn_pairwise_sqdist: facenet/statistics.py:22-57 (pairwise_similarities): metric 0 -> 2(1-a.b) with the
+ * dot clipped to [-1,1], metric 1 -> arccos, metric 2 -> |a|^2+|b|^2-2a.b (un-normalised inputs).
+ * range[2] receives min/max of the raw dot products (the reference's +-(1+atol) check is done by the caller).
+ * Triplet selection / loss are build-defined (arXiv 1503.03832 sec. 3). */
+int fn_pairwise_sqdist(const float* xa, const float* xb, float* out, float* range, int n, int m, int E, int metric, void* stream);
+int fn_select_triplets(const float* dist, const int32_t* labels, int n, float alpha, int nrof_triplets, uint32_t seed,
+                       int semi_hard, int32_t* triplets, int32_t* info, void* stream);
+int fn_triplet_loss_fwd_bwd(const float* emb, float* demb, float* loss, int T, int E, float alpha, void* stream);
+
+/* ---- softmax classifier loss: apps/train_softmax.py:91 (SparseCategoricalCrossentropy(from_logits)) */
+int fn_softmax_xent_fwd_bwd(const float* logits, int ld, const int32_t* labels, float* loss, void* dlogits_lp, int ld_d, float* dbias, int N,
+                            int C, float grad_scale, int dtype, void* stream);
+
+/* ---- optimiser: tf.keras.optimizers.Adam(epsilon=0.1) apps/train_softmax.py:92 + Keras L2(5e-4) (:65) ----
+ * hyper = device fp32[4] {lr, beta1^t, beta2^t, grad_scale}; the kernel advances beta powers itself (graph replay safe).
+ * Elements [0, n_decay) get the coupled L2 term g += 2*l2*w.  w_lp receives the low-precision copy of w[0, n_lp). */
+int fn_adam_keras(float* w, const float* g, float* m, float* v, void* w_lp, long n_lp, long n, long n_decay, float* hyper, float beta1,
+                  float beta2, float eps, float l2, int dtype, void* stream);
+int fn_adam_tick(float* hyper, float beta1, float beta2, void* stream);
+
+/* ---- weight packs ----------------------------------------------------------------------------------
+ * table = device int32 [n_layers][8] {w_off, cout, ktot, taps, cin, bn_off(-1 none), fold_bias_off, 0}.
+ * fn_pack_transpose: wt[cin][tap][cout] = w[cout][tap][cin] (dgrad operand) for every layer.
+ * fn_fold_bn: wf = lp(w * rsqrt(var+eps)[cout]), bias = beta - mean*rsqrt(var+eps)   (facenet/tfutils.py:244-250) */
+int fn_pack_transpose(const void* w_lp, void* wt_lp, const int32_t* table, int n_layers, int max_layer_elems, int dtype, void* stream);
+int fn_fold_bn(const float* w, void* wf_lp, float* fold_bias, const float* beta, const float* moving_mean, const float* moving_var,
+               const int32_t* table, int n_layers, int max_layer_elems, float eps, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,145 @@
+"""Implicit-GEMM convolution kernels (fwd / dgrad / wgrad) against an fp32 CPU convolution on the same
+rounded operands.  Shapes cover every kernel size / stride / padding of Inception-ResNet-v1, ragged M,
+odd channel counts (80, 10575-like), channel slices (ld > C) and the fused epilogues."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from facenet_amd import _lib
+from tests.util import conv_desc, lp_dtype, ptr, ref_conv, rel_err, stream
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # N, H, W, Cin, Cout, kh, kw, stride, ph, pw
+    (2, 19, 19, 8, 32, 3, 3, 2, 0, 0),     # stem 1a-like (Cin padded 3->8)
+    (2, 15, 15, 32, 64, 3, 3, 1, 0, 0),    # 2b
+    (3, 9, 9, 64, 80, 1, 1, 1, 0, 0),      # 3b (Cout=80)
+    (2, 11, 11, 80, 192, 3, 3, 1, 0, 0),   # 4a (Cin=80: K tiles straddle taps)
+    (2, 17, 17, 256, 32, 1, 1, 1, 0, 0),   # block35 1x1
+    (2, 17, 17, 32, 32, 3, 3, 1, 1, 1),    # block35 3x3 same
+    (2, 17, 17, 192, 256, 3, 3, 2, 0, 0),  # reduction stride-2
+    (3, 8, 8, 128, 128, 1, 7, 1, 0, 3),    # block17 1x7
+    (3, 8, 8, 128, 128, 7, 1, 1, 3, 0),    # block17 7x1
+    (5, 3, 3, 192, 192, 1, 3, 1, 0, 1),    # block8 1x3
+    (5, 3, 3, 192, 192, 3, 1, 1, 1, 0),    # block8 3x1
+    (5, 3, 3, 384, 1792, 1, 1, 1, 0, 0),   # block8 up
+    (7, 1, 1, 1792, 128, 1, 1, 1, 0, 0),   # Dense 1792 -> E
+]
+
+
+def _mk(shape, dt, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(lp_dtype(dt)).cuda()
+
+
+@pytest.mark.parametrize("dt", [_lib.FN_BF16, _lib.FN_F16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd(lib, case, dt):
+    N, H, W, Cin, Cout, kh, kw, s, ph, pw = case
+    x = _mk((N, H, W, Cin), dt, seed=1)
+    w = _mk((Cout, kh, kw, Cin), dt, 0.1, seed=2)
+    d = conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt)
+    y = torch.full((N, d.OH, d.OW, Cout), 7.0, dtype=lp_dtype(dt), device="cuda")
+    stats = torch.zeros(2 * Cout, dtype=torch.float32, device="cuda")
+    d.x, d.w, d.y, d.stats, d.stats_sq_off = ptr(x), ptr(w), ptr(y), ptr(stats), Cout
+    _lib.check(lib.fn_conv2d_fwd(C.byref(d), stream()))
+    torch.cuda.synchronize()
+    ref = ref_conv(x, w, s, ph, pw)
+    assert rel_err(y, ref) < (6e-3 if dt == _lib.FN_BF16 else 8e-4)
+    # BatchNorm statistics come from the fp32 accumulators
+    M = N * d.OH * d.OW
+    s_ref = ref.reshape(M, Cout).sum(0)
+    q_ref = (ref.reshape(M, Cout) ** 2).sum(0)
+    assert torch.allclose(stats[:Cout].cpu(), s_ref, rtol=2e-3, atol=2e-3 * float(s_ref.abs().max()))
+    assert torch.allclose(stats[Cout:].cpu(), q_ref, rtol=2e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("dt", [_lib.FN_BF16])
+def test_conv_fwd_epilogues_and_slices(lib, dt):
+    """bias + residual scale-add + ReLU, output into a channel slice, input from a channel slice, fp32 output."""
+    N, H, W, Cin, Cout = 2, 8, 8, 64, 96
+    xb = _mk((N, H, W, 160), dt, seed=3)           # input slice [32:96] of a 160-channel buffer
+    w = _mk((Cout, 1, 1, Cin), dt, 0.2, seed=4)
+    bias = torch.randn(Cout).cuda()
+    res = _mk((N, H, W, Cout), dt, seed=5)
+    yb = torch.zeros(N, H, W, 256, dtype=lp_dtype(dt), device="cuda")   # output slice [128:224]
+    d = conv_desc(N, H, W, Cin, Cout, 1, 1, 1, 0, 0, dt, ld_x=160, ld_y=256)
+    d.x, d.w, d.y, d.bias, d.resid, d.ld_res, d.scale, d.relu = ptr(xb, 32), ptr(w), ptr(yb, 128), ptr(bias), ptr(res), Cout, 0.17, 1
+    _lib.check(lib.fn_conv2d_fwd(C.byref(d), stream()))
+    torch.cuda.synchronize()
+    ref = torch.relu(res.float().cpu() + 0.17 * (ref_conv(xb[..., 32:96], w, 1, 0, 0) + bias.cpu()))
+    assert rel_err(yb[..., 128:224], ref) < 6e-3
+    assert float(yb[..., :128].abs().max()) == 0 and float(yb[..., 224:].abs().max()) == 0   # neighbours untouched
+    # fp32 output with a ragged Cout (classifier-like: 203 of 208 columns)
+    Cr, Cp = 203, 208
+    w2 = _mk((Cp, 1, 1, Cin), dt, 0.2, seed=6)
+    w2[Cr:] = 0
+    x2 = _mk((5, 1, 1, Cin), dt, seed=7)
+    y2 = torch.zeros(5, Cp, dtype=torch.float32, device="cuda")
+    d2 = conv_desc(5, 1, 1, Cin, Cp, 1, 1, 1, 0, 0, dt)
+    d2.x, d2.w, d2.y, d2.out_f32 = ptr(x2), ptr(w2), ptr(y2), 1
+    _lib.check(lib.fn_conv2d_fwd(C.byref(d2), stream()))
+    torch.cuda.synchronize()
+    assert rel_err(y2.view(5, 1, 1, Cp), ref_conv(x2, w2, 1, 0, 0)) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [_lib.FN_BF16, _lib.FN_F16])
+@pytest.mark.parametrize("case", CASES[1:])
+def test_conv_dgrad(lib, case, dt):
+    N, H, W, Cin, Cout, kh, kw, s, ph, pw = case
+    d = conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt)
+    dy = _mk((N, d.OH, d.OW, Cout), dt, seed=11)
+    w = _mk((Cout, kh, kw, Cin), dt, 0.1, seed=12)
+    wt = torch.zeros_like(w).view(-1)
+    table = torch.tensor([[0, Cout, kh * kw * Cin, kh * kw, Cin, -1, -1, 0]], dtype=torch.int32, device="cuda")
+    _lib.check(lib.fn_pack_transpose(ptr(w), ptr(wt), ptr(table), 1, w.numel(), dt, stream()))
+    dx = torch.full((N, H, W, Cin), 3.0, dtype=lp_dtype(dt), device="cuda")
+    d.y, d.w, d.dx = ptr(dy), ptr(wt), ptr(dx)
+    _lib.check(lib.fn_conv2d_dgrad(C.byref(d), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(wt.view(Cin, kh * kw, Cout).cpu(), w.view(Cout, kh * kw, Cin).permute(2, 1, 0).cpu())
+    xr = torch.zeros(N, Cin, H, W, requires_grad=True)
+    yr = torch.nn.functional.conv2d(xr, w.float().cpu().permute(0, 3, 1, 2), None, stride=s, padding=(ph, pw))
+    yr.backward(dy.float().cpu().permute(0, 3, 1, 2))
+    ref = xr.grad.permute(0, 2, 3, 1)
+    assert rel_err(dx, ref) < (6e-3 if dt == _lib.FN_BF16 else 8e-4)
+    # accumulate mode adds on top
+    d.accumulate = 1
+    _lib.check(lib.fn_conv2d_dgrad(C.byref(d), stream()))
+    torch.cuda.synchronize()
+    assert rel_err(dx, 2 * ref) < (1e-2 if dt == _lib.FN_BF16 else 2e-3)
+
+
+@pytest.mark.parametrize("dt", [_lib.FN_BF16, _lib.FN_F16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_wgrad(lib, case, dt):
+    N, H, W, Cin, Cout, kh, kw, s, ph, pw = case
+    d = conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt)
+    x = _mk((N, H, W, Cin), dt, seed=21)
+    dy = _mk((N, d.OH, d.OW, Cout), dt, seed=22)
+    dw = torch.zeros(Cout, kh, kw, Cin, dtype=torch.float32, device="cuda")
+    d.x, d.y, d.dw = ptr(x), ptr(dy), ptr(dw)
+    _lib.check(lib.fn_conv2d_wgrad(C.byref(d), stream()))
+    torch.cuda.synchronize()
+    wr = torch.zeros(Cout, Cin, kh, kw, requires_grad=True)
+    yr = torch.nn.functional.conv2d(x.float().cpu().permute(0, 3, 1, 2), wr, None, stride=s, padding=(ph, pw))
+    yr.backward(dy.float().cpu().permute(0, 3, 1, 2))
+    ref = wr.grad.permute(0, 2, 3, 1)
+    assert rel_err(dw, ref) < 2e-5     # operands are exact in low precision, accumulation is fp32
+    # forced split-K
+    dw.zero_()
+    d.splits = 3
+    _lib.check(lib.fn_conv2d_wgrad(C.byref(d), stream()))
+    torch.cuda.synchronize()
+    assert rel_err(dw, ref) < 2e-5
+
+
+def test_conv_rejects_bad_geometry(lib):
+    d = conv_desc(1, 8, 8, 12, 16, 3, 3, 1, 0, 0, _lib.FN_BF16)   # Cin not a multiple of 8
+    x = torch.zeros(1, 8, 8, 12, dtype=torch.bfloat16, device="cuda")
+    d.x = d.w = d.y = ptr(x)
+    with pytest.raises(ValueError):
+        _lib.check(lib.fn_conv2d_fwd(C.byref(d), stream()))
