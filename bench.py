@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of 160x160 Inception-ResNet-v1 triplet training (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = the whole hot path on one batch of synthetic input already resident in HBM:
+  mining forward over a P x K = 45 x 4 = 180 image pool (BN-folded f16 inference path) -> [180,180] distance
+  matrix -> online triplet selection (alpha 0.2) -> gather of the 90-image (30 triplets) train batch ->
+  forward(training=True) -> l2_normalize -> triplet loss -> backward -> Keras Adam(eps=0.1) + L2 -> weight packs.
+Nothing is skipped inside the timed region.  `value` counts the 90 TRAINED images per GPU per step
+(BASELINE.json configs[1]); `value_train_only` times the same step without the mining forward.
+
+Weak scaling: every rank trains its own 90-image batch (per-replica BatchNorm, local mining); gradients are summed
+by RCCL all-reduce in backward-ordered buckets overlapped with backward.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FWD_GFLOP_PER_IMAGE = 2.802       # SURVEY.md 8d / BASELINE.md section 2 (E=128)
+MFMA_PEAK_TFLOPS = 2500.0         # dense bf16/f16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def conv_flops(d, op):
+    """Algorithmic FLOPs of one launch: 2 * MACs of the layer (SURVEY.md shape table); dgrad/wgrad = the same MACs."""
+    return 2.0 * d.N * d.OH * d.OW * d.Cout * d.KH * d.KW * d.Cin
+
+
+def time_ops_individually(ops, stream, lib, reps=3):
+    """HIP events around every launch (on the stream the kernels run on); returns per-op best-of-reps milliseconds."""
+    from facenet_amd import _lib
+    times = [float("inf")] * len(ops)
+    for _ in range(reps):
+        evs = []
+        for op in ops:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = op.fn(*op.args, stream)
+            b.record()
+            if rc:
+                _lib.check(rc, op.name)
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(evs):
+            times[i] = min(times[i], a.elapsed_time(b))
+    return times
+
+
+def kernel_roofline(trainer, miner, lib):
+    """Attribute event-timed launches to kernel instantiations; report the dominant one against its roofline."""
+    import ctypes as C
+    net = trainer.net
+    st = net.stream()
+    groups = {}
+    all_ops = list(miner.ops) + list(trainer.plan.fwd) + list(trainer.loss_ops) + list(trainer.plan.bwd) + list(trainer.opt_ops)
+    trainer._zero()
+    t = time_ops_individually(all_ops, st, lib)
+    dtn = {torch.bfloat16: "__bf16", torch.float16: "_Float16"}
+    for op, ms in zip(all_ops, t):
+        kind = op.name.split(":")[0]
+        if kind in ("conv_fwd", "conv_dgrad", "conv_wgrad") and op.keep:
+            d = op.keep[0]
+            opi = {"conv_fwd": 0, "conv_dgrad": 1, "conv_wgrad": 2}[kind]
+            v = lib.fn_conv2d_variant(C.byref(d), opi)
+            tname = "__bf16" if d.dtype == 0 else "_Float16"
+            if opi == 2:
+                key = f"conv_wgrad_kernel<{tname},{v // 1000},{v % 1000}>"
+            else:
+                key = f"conv_igemm_kernel<{tname},{v // 1000},{v % 1000}>"
+            g = groups.setdefault(key, dict(ms=0.0, flops=0.0, launches=0, bound="mfma"))
+            g["flops"] += conv_flops(d, opi)
+        else:
+            g = groups.setdefault(kind, dict(ms=0.0, flops=0.0, launches=0, bound="hbm"))
+        g["ms"] += ms
+        g["launches"] += 1
+    total_ms = sum(g["ms"] for g in groups.values())
+    top = sorted(groups.items(), key=lambda kv: -kv[1]["ms"])
+    name, g = next((kv for kv in top if kv[1]["flops"] > 0), top[0])
+    achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+    roof = {
+        "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "launches_per_step": g["launches"], "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
+        "share_of_step_kernel_time": round(g["ms"] / total_ms, 3),
+        "flop_per_launch_avg": round(g["flops"] / g["launches"], 0),
+    }
+    breakdown = [{"kernel": k, "ms": round(v["ms"], 3), "launches": v["launches"],
+                  **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} if v["flops"] > 0 and v["ms"] > 0 else {})}
+                 for k, v in top[:12]]
+    return roof, breakdown, total_ms
+
+
+def cpu_baseline(pool_n=60, batch=30, E=128, reps=2):
+    """The oracle (a port: PyTorch-CPU fp32 restatement) timed on this box's host cores on a bounded sample of the same
+    workload: mining forward over a 60-image pool + one 30-image (10 triplets) train step incl. Keras Adam."""
+    from oracle import facenet_oracle as fo
+    params, trainable, regularized = fo.build_params(E, seed=0)
+    rng = np.random.default_rng(0)
+    pool = rng.integers(0, 256, (pool_n, 160, 160, 3), dtype=np.uint8)
+    labels = np.repeat(np.arange(pool_n // 4), 4)
+    opt = fo.AdamKeras(trainable, params, lr=0.05)
+
+    def one():
+        with torch.no_grad():
+            emb = fo.Oracle(params).forward(pool, training=False).numpy()
+        dist = fo.squared_distance_matrix(emb)
+        trip = fo.select_triplets(dist, labels, 0.2, batch // 3, seed=0)
+        x = pool[trip.reshape(-1)]
+        _, _, grads, stats, _ = fo.train_step_grads(params, trainable, regularized, x, "triplet", alpha=0.2)
+        opt.step(params, grads)
+        for k, v in stats.items():
+            params[k].copy_(v)
+    one()  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one()
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(batch / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} steps of (mining forward {pool_n} images + triplet train step on {batch} images), fp32 PyTorch-CPU oracle, "
+                      f"{dt:.2f} s/step, host has {os.cpu_count()} logical cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-graph", action="store_true", help="replay the launch list eagerly instead of through HIP graphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=90)
+    ap.add_argument("--pool", type=int, default=180)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # backend "nccl" is RCCL on ROCm
+        pg = dist.group.WORLD
+
+    from facenet_amd import _lib
+    from facenet_amd.engine import Network
+    from facenet_amd.train import Trainer, TripletMiner
+    lib = _lib.load()
+
+    E, B, POOL = 128, args.batch, args.pool
+    net = Network(embedding_size=E, device=str(dev), train_dtype=torch.bfloat16, infer_dtype=torch.float16, seed=0)
+    trainer = Trainer(net, batch=B, loss="triplet", alpha=0.2, lr=0.05, world_size=world, process_group=pg)
+    labels = np.repeat(np.arange(POOL // 4), 4)
+    miner = TripletMiner(net, POOL, labels, B // 3, alpha=0.2, seed=1000 * rank)
+    miner.build(trainer.plan.images)
+    # synthetic pools resident in HBM before the timed region (seeds offset by rank)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    pools = [torch.randint(0, 256, (POOL, 160, 160, 3), dtype=torch.uint8, device=dev, generator=g) for _ in range(4)]
+
+    # ---- capture ---------------------------------------------------------------------------------
+    miner.plan.images.copy_(pools[0])
+    miner.run()
+    trainer.step_eager()
+    torch.cuda.synchronize()
+    mine_graph = None
+    if not args.no_graph:
+        from facenet_amd.train import GraphRunner
+        mine_graph = GraphRunner(dev).capture(lambda st: miner.run(st))
+        trainer.capture()
+
+    def step(i, with_mining=True):
+        if with_mining:
+            miner.plan.images.copy_(pools[i % len(pools)])
+            if mine_graph is not None:
+                mine_graph.replay()
+            else:
+                miner.run()
+        trainer.step()
+
+    def timed(n, with_mining):
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(i, with_mining)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    for i in range(args.warmup):
+        step(i)
+    elapsed = timed(args.steps, True)
+    n2 = max(5, args.steps // 2)
+    elapsed_train = timed(n2, False)
+    loss = trainer.loss_value()
+
+    out = None
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        value = B * world * args.steps / elapsed
+        out = {
+            "metric": "images/sec (160x160 triplet train)", "value": round(value, 1), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Inception-ResNet-v1 triplet-loss train, batch=90 (30 triplets), bf16, per GPU; "
+                                   "mining forward over a 45x4=180 image pool (f16 inference path) + on-device selection inside the step",
+                       "global_batch": B * world, "image": "160x160x3 uint8", "embedding": E, "alpha": 0.2,
+                       "optimizer": "Keras Adam eps=0.1 + L2 5e-4", "parallelism": f"dp{world}",
+                       "hip_graph": not args.no_graph},
+            "value_train_only": round(B * world * n2 / elapsed_train, 1),
+            "ms_per_step_train_only": round(1e3 * elapsed_train / n2, 3),
+            "final_loss": round(loss, 5),
+            "model_tflops": round((3 * B + POOL) * FWD_GFLOP_PER_IMAGE * 1e-3 / (ms * 1e-3), 1),
+        }
+    if rank == 0 and world == 1:
+        roof, breakdown, kernel_ms = kernel_roofline(trainer, miner, lib)
+        out["roofline"] = roof
+        out["kernel_breakdown"] = breakdown
+        out["sum_kernel_ms_eager"] = round(kernel_ms, 3)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -314,16 +314,22 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
     return check_launch("conv_igemm");
 }
 
-template <typename T> static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
-    // BN: smallest padded width, ties -> larger tile.
-    int bn = 128;
-    long best = (long)cdiv(a.NOUT, 128) * 128;
+// Tile choice.  BN: smallest padded width, ties -> larger tile.  BM=64 when a 128-row tiling cannot even give
+// one block per CU.
+static void choose_conv_tile(int M, int NOUT, int& bm, int& bn) {
+    bn = 128;
+    long best = (long)cdiv(NOUT, 128) * 128;
     for (int c : {64, 32}) {
-        const long w = (long)cdiv(a.NOUT, c) * c;
+        const long w = (long)cdiv(NOUT, c) * c;
         if (w < best) { best = w; bn = c; }
     }
-    // BM=64 when a 128-row tiling cannot even give one block per CU.
-    const bool small = (long)cdiv(a.M, 128) * cdiv(a.NOUT, bn) < 256;
+    bm = ((long)cdiv(M, 128) * cdiv(NOUT, bn) < 256) ? 64 : 128;
+}
+
+template <typename T> static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
+    int bm, bn;
+    choose_conv_tile(a.M, a.NOUT, bm, bn);
+    const bool small = bm == 64;
     if (!small) {
         if (bn == 128) return launch_conv<T, 128, 128, 2, 2>(a, st);
         if (bn == 64) return launch_conv<T, 128, 64, 2, 2>(a, st);
@@ -527,9 +533,14 @@ template <typename T, int BMW, int BNW> static int launch_wgrad(const WgradArgs&
     return check_launch("conv_wgrad");
 }
 
+static void choose_wgrad_tile(int Cout, int KTOT, int& bmw, int& bnw) {
+    bmw = Cout <= 32 ? 32 : (Cout <= 64 || Cout % 128 != 0 ? 64 : 128);
+    bnw = (KTOT <= 64 || (cdiv(KTOT, 128) * 128 - KTOT) > 32) ? 64 : 128;
+}
+
 template <typename T> static int dispatch_wgrad(WgradArgs& a, int want_splits, hipStream_t st) {
-    const int bmw = a.Cout <= 32 ? 32 : (a.Cout <= 64 || a.Cout % 128 != 0 ? 64 : 128);
-    const int bnw = (a.KTOT <= 64 || (cdiv(a.KTOT, 128) * 128 - a.KTOT) > 32) ? 64 : 128;
+    int bmw, bnw;
+    choose_wgrad_tile(a.Cout, a.KTOT, bmw, bnw);
     const long tiles = (long)cdiv(a.KTOT, bnw) * cdiv(a.Cout, bmw);
     int splits = want_splits;
     if (splits <= 0) {
@@ -596,4 +607,15 @@ extern "C" int fn_conv2d_wgrad(const fn_conv_desc* d, void* stream) {
     a.inv_ow = 1.0f / (float)d->OW; a.inv_ohw = 1.0f / (float)(d->OH * d->OW);
     return d->dtype == FN_BF16 ? dispatch_wgrad<__bf16>(a, d->splits, (hipStream_t)stream)
                                : dispatch_wgrad<_Float16>(a, d->splits, (hipStream_t)stream);
+}
+
+// Which kernel instantiation a descriptor dispatches to: returns BM*1000 + BN (op 0 = fwd, 1 = dgrad) or
+// BMW*1000 + BNW (op 2 = wgrad).  Lets bench.py attribute HIP-event timings to the kernel names rocprofv3 reports.
+extern "C" int fn_conv2d_variant(const fn_conv_desc* d, int op) {
+    if (!d || op < 0 || op > 2) return FN_EINVAL;
+    int a, b;
+    if (op == 0) choose_conv_tile(d->N * d->OH * d->OW, d->Cout, a, b);
+    else if (op == 1) choose_conv_tile(d->N * d->H * d->W, d->Cin, a, b);
+    else choose_wgrad_tile(d->Cout, d->KH * d->KW * d->Cin, a, b);
+    return a * 1000 + b;
 }

@@ -60,26 +60,25 @@ template <typename T, typename SRC>
 __global__ __launch_bounds__(256) void img_apply_kernel(const SRC* __restrict__ img, unsigned short* __restrict__ out,
                                                         const unsigned* __restrict__ work, int HW, int mode) {
     const int n = blockIdx.y;
-    float a, b;  // y = a*x + b
-    if (mode == 0) {  // (2x - (min+max)) / max(max-min, 1e-3)   facenet.py:72-77
+    // same operation order as the reference so that exact cases (constant images) stay exact:
+    //   mode 0: (2x - (min+max)) / max(max-min, 1e-3)                      facenet.py:72-77
+    //   mode 1: (x - mean) / max(std, 1/sqrt(numel))  per_image_standardization   facenet.py:79-80
+    float mul, sub, den;
+    if (mode == 0) {
         const float mx = ord2f(work[4 * n + 0]), mn = -ord2f(work[4 * n + 1]);
-        const float rng = fmaxf(mx - mn, 1e-3f);
-        a = 2.f / rng;
-        b = -(mn + mx) / rng;
-    } else {          // per_image_standardization: (x-mean)/max(std, 1/sqrt(numel))   facenet.py:79-80
+        mul = 2.f; sub = mn + mx; den = fmaxf(mx - mn, 1e-3f);
+    } else {
         const float cnt = (float)HW * 3.f;
         const float mean = __uint_as_float(work[4 * n + 2]) / cnt;
         const float var = fmaxf(__uint_as_float(work[4 * n + 3]) / cnt - mean * mean, 0.f);
-        const float sd = fmaxf(sqrtf(var), rsqrtf(cnt));
-        a = 1.f / sd;
-        b = -mean / sd;
+        mul = 1.f; sub = mean; den = fmaxf(sqrtf(var), rsqrtf(cnt));
     }
     const SRC* p = img + (long)n * HW * 3;
     unsigned short* o = out + (long)n * HW * 8;
     for (int px = blockIdx.x * 256 + threadIdx.x; px < HW; px += gridDim.x * 256) {
         float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) v[c] = fmaf(a, (float)p[px * 3 + c], b);
+        for (int c = 0; c < 3; ++c) v[c] = (mul * (float)p[px * 3 + c] - sub) / den;
         *reinterpret_cast<u32x4*>(o + (long)px * 8) = pack8<T>(v);
     }
 }

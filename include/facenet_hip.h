@@ -59,6 +59,8 @@ typedef struct fn_conv_desc {
 int fn_conv2d_fwd(const fn_conv_desc* d, void* stream);
 int fn_conv2d_dgrad(const fn_conv_desc* d, void* stream);
 int fn_conv2d_wgrad(const fn_conv_desc* d, void* stream);
+/* tile variant the descriptor dispatches to (op 0 fwd, 1 dgrad, 2 wgrad): BM*1000+BN; measurement aid only */
+int fn_conv2d_variant(const fn_conv_desc* d, int op);
 
 /* ---- input normalisation: facenet/facenet.py:67-86 (ImageProcessing.call) -------
  * u8 NHWC [N,H,W,3] -> low precision [N,H,W,8] (channels 3..7 zero), mode 0 = per-image

@@ -58,65 +58,96 @@ def test_forward_embeddings_c1(variant, E):
         assert torch.allclose(emb.norm(dim=1), torch.ones(16), atol=1e-5)
 
 
-def _grad_check(net, grads_ref, G, tol_w, tol_small):
+def _rel(a, b):
+    return (a - b).norm().item() / (b.norm().item() + 1e-12)
+
+
+def _grad_report(net, G, g32, gq):
+    """Per-parameter relative errors: HIP vs fp32 oracle, HIP vs storage-rounding oracle, rounding oracle vs fp32."""
     mine = net.export_keras_grads(G)
-    worst = ("", 0.0)
-    for k, g in grads_ref.items():
-        denom = g.norm().item()
-        err = (mine[k] - g).norm().item() / (denom + 1e-12)
-        if err > worst[1]:
-            worst = (k, err)
-        lim = tol_w if k.endswith("kernel") else tol_small
-        assert err < lim or (mine[k] - g).abs().max().item() < 1e-6, f"{k}: rel err {err:.3e} (|g|={denom:.3e})"
-    return worst
+    keys = [k for k, g in g32.items() if g.norm().item() > 1e-4]
+    e_hip32 = np.array([_rel(mine[k], g32[k]) for k in keys])
+    e_hipq = np.array([_rel(mine[k], gq[k]) for k in keys])
+    e_q32 = np.array([_rel(gq[k], g32[k]) for k in keys])
+    flat = lambda d: torch.cat([d[k].reshape(-1) for k in keys])
+    cos = torch.nn.functional.cosine_similarity(flat(mine), flat(g32), dim=0).item()
+    return mine, keys, e_hip32, e_hipq, e_q32, cos
 
 
-def test_triplet_train_step_gradients():
+def _train_once(params, x, loss, dt, **kw):
+    E = params["features/logits/kernel"].shape[1]
+    ncls = params["classifier/logits/kernel"].shape[1] if "classifier/logits/kernel" in params else None
+    net = Network(embedding_size=E, device="cuda:0", train_dtype=dt, nrof_classes=ncls)
+    net.load_keras_params(params)
+    tr = Trainer(net, batch=x.shape[0], loss=loss, alpha=0.2, l2=0.0)
+    tr.set_images(torch.from_numpy(x), torch.from_numpy(kw["labels"]) if "labels" in kw else None)
+    st = net.stream()
+    tr._zero()
+    tr.plan.run_ops(tr.plan.fwd, st)
+    tr.plan.run_ops(tr.loss_ops, st)
+    tr.plan.run_ops(tr.plan.bwd, st)
+    torch.cuda.synchronize()
+    return net, tr
+
+
+# Gradients of a freshly initialised BatchNorm network at batch 9 are ill-conditioned: rounding activations to
+# f16 / bf16 alone (tests/quant_oracle.py, everything else fp32 autograd) moves them by ~15 % / ~40 % relative to
+# fp32, because each small-batch BN backward projects most of the incoming gradient away.  The bar is therefore:
+# the HIP path must be as close to the fp32 oracle as that ideal low-precision-storage model is (x1.25 + 0.02),
+# closer to the rounding model than the rounding model is to fp32, and tight where no BN backward intervenes.
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_triplet_train_step_gradients(dt):
     """forward(training=True) + l2_normalize + triplet loss + backward vs autograd on the oracle (batch 9 = 3 triplets)."""
+    from tests.quant_oracle import quant_train_step_grads
+    from tests.util import structured_images
     E, N = 128, 9
-    params, trainable, regularized = fo.build_params(E, seed=0)
-    x = _images(N, seed=3)
-    loss_ref, _, grads_ref, new_stats, emb_ref = fo.train_step_grads(params, trainable, [], x, "triplet", alpha=0.2)
-    net = Network(embedding_size=E, device="cuda:0")
-    net.load_keras_params(params)
-    tr = Trainer(net, batch=N, loss="triplet", alpha=0.2, l2=0.0)
-    tr.set_images(torch.from_numpy(x))
-    st = net.stream()
-    tr._zero()
-    tr.plan.run_ops(tr.plan.fwd, st)
-    tr.plan.run_ops(tr.loss_ops, st)
-    tr.plan.run_ops(tr.plan.bwd, st)
-    torch.cuda.synchronize()
+    params, trainable, _ = fo.build_params(E, seed=0)
+    x = structured_images(N, seed=3)
+    loss_ref, _, g32, new_stats, emb_ref = fo.train_step_grads(params, trainable, [], x, "triplet", alpha=0.2)
+    loss_q, gq, emb_q = quant_train_step_grads(params, trainable, x, "triplet", dt)
+    net, tr = _train_once(params, x, "triplet", dt)
     emb = tr.emb.float().cpu()
-    rel = ((emb - emb_ref).norm() / emb_ref.norm()).item()
-    print(f"train-mode embedding rel err {rel:.3e}; loss {tr.loss_value():.5f} vs {loss_ref:.5f}")
-    assert rel < 3e-2
-    assert abs(tr.loss_value() - loss_ref) < 2e-2 * max(1.0, abs(loss_ref))
-    worst = _grad_check(net, grads_ref, tr.G, tol_w=0.12, tol_small=0.12)
-    print("worst gradient", worst)
-    # moving statistics follow momentum 0.99 with the biased batch variance
-    mine = net.export_keras_params()
+    f16 = dt == torch.float16
+    print(f"{dt}: train-mode embedding rel err vs fp32 {_rel(emb, emb_ref):.3e} (rounding model {_rel(emb_q, emb_ref):.3e}); "
+          f"loss {tr.loss_value():.5f} fp32 {loss_ref:.5f} rounding {loss_q:.5f}")
+    assert _rel(emb, emb_ref) < 1.25 * _rel(emb_q, emb_ref) + 5e-3
+    assert abs(tr.loss_value() - loss_ref) < (1e-2 if f16 else 5e-2)
+    mine, keys, e_hip32, e_hipq, e_q32, cos = _grad_report(net, tr.G, g32, gq)
+    print(f"  grads: median rel err HIP-fp32 {np.median(e_hip32):.3f}  HIP-rounding {np.median(e_hipq):.3f}  rounding-fp32 {np.median(e_q32):.3f}; "
+          f"max {e_hip32.max():.3f}/{e_q32.max():.3f}; cosine {cos:.4f}")
+    assert np.median(e_hip32) < 1.25 * np.median(e_q32) + 0.02
+    assert e_hip32.max() < 1.25 * e_q32.max() + 0.05
+    assert np.median(e_hipq) < np.median(e_q32)
+    assert cos > (0.98 if f16 else 0.88)
+    # no BatchNorm backward between the loss and these two: tight
+    for k in ("features/logits/kernel", "block8_2/up/kernel"):
+        assert _rel(mine[k], g32[k]) < (0.03 if f16 else 0.2), k
+    # moving statistics follow momentum 0.99 with the biased batch variance (SURVEY.md hazard 3)
+    stats = net.export_keras_params()
     for k in ("conv2d/Conv2d_1a_3x3/bn/moving_mean", "block17/3/tower_conv1/Conv2d_0b_1x7/bn/moving_variance", "features/bn/moving_mean"):
-        assert torch.allclose(mine[k], new_stats[k], rtol=3e-2, atol=3e-3), k
+        assert torch.allclose(stats[k], new_stats[k], rtol=3e-2, atol=3e-3), k
 
 
-def test_softmax_train_step_gradients():
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_softmax_train_step_gradients(dt):
     """apps/train_softmax.py:49-104 step: classifier Dense + sparse softmax cross-entropy (batch 8, 37 classes)."""
+    from tests.quant_oracle import quant_train_step_grads
+    from tests.util import structured_images
     E, N, Cc = 128, 8, 37
-    params, trainable, regularized = fo.build_params(E, seed=0, nrof_classes=Cc)
-    x = _images(N, seed=4)
+    params, trainable, _ = fo.build_params(E, seed=0, nrof_classes=Cc)
+    x = structured_images(N, seed=4)
     labels = np.random.default_rng(5).integers(0, Cc, N)
-    loss_ref, _, grads_ref, _, _ = fo.train_step_grads(params, trainable, [], x, "softmax", labels=labels)
-    net = Network(embedding_size=E, device="cuda:0", nrof_classes=Cc)
-    net.load_keras_params(params)
-    tr = Trainer(net, batch=N, loss="softmax", l2=0.0)
-    tr.set_images(torch.from_numpy(x), torch.from_numpy(labels))
-    st = net.stream()
-    tr._zero()
-    tr.plan.run_ops(tr.plan.fwd, st)
-    tr.plan.run_ops(tr.loss_ops, st)
-    tr.plan.run_ops(tr.plan.bwd, st)
-    torch.cuda.synchronize()
-    print(f"softmax loss {tr.loss_value():.5f} vs {loss_ref:.5f}")
-    assert abs(tr.loss_value() - loss_ref) < 2e-2 * max(1.0, abs(loss_ref))
-    _grad_check(net, grads_ref, tr.G, tol_w=0.12, tol_small=0.12)
+    loss_ref, _, g32, _, _ = fo.train_step_grads(params, trainable, [], x, "softmax", labels=labels)
+    loss_q, gq, _ = quant_train_step_grads(params, trainable, x, "softmax", dt, labels=labels)
+    net, tr = _train_once(params, x, "softmax", dt, labels=labels)
+    f16 = dt == torch.float16
+    print(f"{dt}: softmax loss {tr.loss_value():.5f} fp32 {loss_ref:.5f} rounding {loss_q:.5f}")
+    assert abs(tr.loss_value() - loss_ref) < (2e-2 if f16 else 8e-2)
+    mine, keys, e_hip32, e_hipq, e_q32, cos = _grad_report(net, tr.G, g32, gq)
+    print(f"  grads: median rel err HIP-fp32 {np.median(e_hip32):.3f}  HIP-rounding {np.median(e_hipq):.3f}  rounding-fp32 {np.median(e_q32):.3f}; cosine {cos:.4f}")
+    assert np.median(e_hip32) < 1.25 * np.median(e_q32) + 0.02
+    assert e_hip32.max() < 1.25 * e_q32.max() + 0.05
+    assert np.median(e_hipq) < np.median(e_q32)
+    assert cos > (0.98 if f16 else 0.88)
+    for k in ("classifier/logits/kernel", "classifier/logits/bias"):
+        assert _rel(mine[k], g32[k]) < (0.02 if f16 else 0.08), k
