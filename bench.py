@@ -59,7 +59,7 @@ def time_ops_individually(ops, stream, lib, reps=3):
     return times
 
 
-def kernel_roofline(trainer, miner, lib):
+def kernel_roofline(trainer, miner, lib, dump=None):
     """Attribute event-timed launches to kernel instantiations; report the dominant one against its roofline."""
     import ctypes as C
     net = trainer.net
@@ -67,8 +67,9 @@ def kernel_roofline(trainer, miner, lib):
     groups = {}
     all_ops = list(miner.ops) + list(trainer.plan.fwd) + list(trainer.loss_ops) + list(trainer.plan.bwd) + list(trainer.opt_ops)
     trainer._zero()
+    torch.cuda.synchronize()
     t = time_ops_individually(all_ops, st, lib)
-    dtn = {torch.bfloat16: "__bf16", torch.float16: "_Float16"}
+    per_op = []
     for op, ms in zip(all_ops, t):
         kind = op.name.split(":")[0]
         if kind in ("conv_fwd", "conv_dgrad", "conv_wgrad") and op.keep:
@@ -82,10 +83,17 @@ def kernel_roofline(trainer, miner, lib):
                 key = f"conv_igemm_kernel<{tname},{v // 1000},{v % 1000}>"
             g = groups.setdefault(key, dict(ms=0.0, flops=0.0, launches=0, bound="mfma"))
             g["flops"] += conv_flops(d, opi)
+            per_op.append(dict(op=op.name, kernel=key, us=round(ms * 1e3, 2), gflop=round(conv_flops(d, opi) / 1e9, 3),
+                               tflops=round(conv_flops(d, opi) / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0,
+                               shape=f"N{d.N} {d.H}x{d.W}x{d.Cin}->{d.OH}x{d.OW}x{d.Cout} k{d.KH}x{d.KW}s{d.stride}"))
         else:
             g = groups.setdefault(kind, dict(ms=0.0, flops=0.0, launches=0, bound="hbm"))
+            per_op.append(dict(op=op.name, us=round(ms * 1e3, 2)))
         g["ms"] += ms
         g["launches"] += 1
+    if dump:
+        with open(dump, "w") as f:
+            json.dump(per_op, f, indent=0)
     total_ms = sum(g["ms"] for g in groups.values())
     top = sorted(groups.items(), key=lambda kv: -kv[1]["ms"])
     name, g = next((kv for kv in top if kv[1]["flops"] > 0), top[0])
@@ -142,6 +150,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=90)
     ap.add_argument("--pool", type=int, default=180)
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the dependency scheduler may use (1 = serial)")
+    ap.add_argument("--dump-ops", default=None, help="write per-launch HIP-event timings (eager) to this JSON file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -165,9 +175,9 @@ def main():
 
     E, B, POOL = 128, args.batch, args.pool
     net = Network(embedding_size=E, device=str(dev), train_dtype=torch.bfloat16, infer_dtype=torch.float16, seed=0)
-    trainer = Trainer(net, batch=B, loss="triplet", alpha=0.2, lr=0.05, world_size=world, process_group=pg)
+    trainer = Trainer(net, batch=B, loss="triplet", alpha=0.2, lr=0.05, world_size=world, process_group=pg, n_streams=args.streams)
     labels = np.repeat(np.arange(POOL // 4), 4)
-    miner = TripletMiner(net, POOL, labels, B // 3, alpha=0.2, seed=1000 * rank)
+    miner = TripletMiner(net, POOL, labels, B // 3, alpha=0.2, seed=1000 * rank, n_streams=args.streams)
     miner.build(trainer.plan.images)
     # synthetic pools resident in HBM before the timed region (seeds offset by rank)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -181,7 +191,9 @@ def main():
     mine_graph = None
     if not args.no_graph:
         from facenet_amd.train import GraphRunner
-        mine_graph = GraphRunner(dev).capture(lambda st: miner.run(st))
+        from facenet_amd.schedule import make_events
+        mine_events = make_events(miner.sched)
+        mine_graph = GraphRunner(dev).capture(lambda: miner.run(mine_events))
         trainer.capture()
 
     def step(i, with_mining=True):
@@ -229,14 +241,14 @@ def main():
                                    "mining forward over a 45x4=180 image pool (f16 inference path) + on-device selection inside the step",
                        "global_batch": B * world, "image": "160x160x3 uint8", "embedding": E, "alpha": 0.2,
                        "optimizer": "Keras Adam eps=0.1 + L2 5e-4", "parallelism": f"dp{world}",
-                       "hip_graph": not args.no_graph},
+                       "hip_graph": not args.no_graph, "streams": args.streams},
             "value_train_only": round(B * world * n2 / elapsed_train, 1),
             "ms_per_step_train_only": round(1e3 * elapsed_train / n2, 3),
             "final_loss": round(loss, 5),
             "model_tflops": round((3 * B + POOL) * FWD_GFLOP_PER_IMAGE * 1e-3 / (ms * 1e-3), 1),
         }
     if rank == 0 and world == 1:
-        roof, breakdown, kernel_ms = kernel_roofline(trainer, miner, lib)
+        roof, breakdown, kernel_ms = kernel_roofline(trainer, miner, lib, args.dump_ops)
         out["roofline"] = roof
         out["kernel_breakdown"] = breakdown
         out["sum_kernel_ms_eager"] = round(kernel_ms, 3)

@@ -25,7 +25,8 @@ class ConvDesc(C.Structure):
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
         ("dtype", C.c_int32), ("ld_x", C.c_int32), ("ld_y", C.c_int32),
         ("relu", C.c_int32), ("accumulate", C.c_int32), ("out_f32", C.c_int32), ("ld_res", C.c_int32),
-        ("scale", C.c_float), ("splits", C.c_int32), ("stats_sq_off", C.c_int32),
+        ("scale", C.c_float), ("splits", C.c_int32), ("stats_sq_off", C.c_int32), ("stats_replicas", C.c_int32),
+        ("stats_rep_stride", C.c_int32),
         ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("dx", C.c_void_p), ("dw", C.c_void_p),
         ("bias", C.c_void_p), ("stats", C.c_void_p), ("resid", C.c_void_p),
     ]
@@ -46,7 +47,7 @@ _SIGNATURES = {
     "fn_image_normalize": [_p, _p, _p, _i, _i, _i, _i, _p],
     "fn_image_normalize_f32": [_p, _p, _p, _i, _i, _i, _i, _p],
     "fn_gather_images": [_p, _p, _p, _i, _i, _p],
-    "fn_bn_relu_train_fwd": [_p, _i, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p],
+    "fn_bn_relu_train_fwd": [_p, _i, _p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p],
     "fn_bn_relu_train_bwd": [_p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p],
     "fn_maxpool3x3s2_fwd": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "fn_maxpool3x3s2_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p],

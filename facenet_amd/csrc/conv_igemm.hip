@@ -41,7 +41,7 @@ struct ConvArgs {
     int relu, accumulate, out_f32;
     float scale;
     int tiles_m, tiles_n;
-    int stats_sq_off;
+    int stats_sq_off, stats_replicas, stats_rep_stride;
 };
 
 // Bijective XCD-aware remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
@@ -60,7 +60,7 @@ __device__ __forceinline__ int ktab_entry(int kgroup, int KTOT, int CS, int KW) 
     return (ky << 24) | (kx << 16) | c;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int BK = 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -111,8 +111,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int dmask = (1 << a.dshift) - 1;
     __syncthreads();
 
-    u32x4 ra[AP], rb[BP];
-    auto load_tile = [&](int kt) {
+    // Two register sets: while tile kt is multiplied out of LDS, tile kt+1 sits in registers (loaded one phase ago)
+    // and the loads of tile kt+2 are in flight -- two global-load latencies are covered per K step, which is what
+    // these launches need: most layers of this network run at <= 1 workgroup per CU, so nothing else hides latency.
+    u32x4 ra0[AP], rb0[BP], ra1[AP], rb1[BP];
+    auto load_tile = [&](int kt, u32x4 (&ra)[AP], u32x4 (&rb)[BP]) {
         const int e = sK[kt * 8 + kg];
         const int ky = (e >> 24) & 0xff, kx = (e >> 16) & 0xff, c = e & 0xffff;
         const int dy = ky * a.sk, dx = kx * a.sk;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             rb[j] = v;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const u32x4 (&ra)[AP], const u32x4 (&rb)[BP]) {
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int r = r0 + 32 * i;
@@ -156,14 +159,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
     const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < ntiles_k; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < ntiles_k) load_tile(kt + 1);  // issue early: latency hides under the MFMAs below
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             vec8 fa[MREP], fb[NREP];
@@ -183,8 +180,35 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < NREP; ++j) acc[i][j] = LP<T>::mfma(fa[i], fb[j], acc[i][j]);
         }
-        if (kt + 1 < ntiles_k) store_tile(buf ^ 1);  // write late: other buffer, last read one barrier ago
+    };
+
+    if constexpr (DEPTH == 2) {
+        load_tile(0, ra0, rb0);
+        if (ntiles_k > 1) load_tile(1, ra1, rb1);
+        store_tile(0, ra0, rb0);
         __syncthreads();
+        for (int kt = 0; kt < ntiles_k; kt += 2) {
+            if (kt + 2 < ntiles_k) load_tile(kt + 2, ra0, rb0);   // in flight across this phase AND the next
+            compute(0);
+            if (kt + 1 < ntiles_k) store_tile(1, ra1, rb1);       // loaded one phase ago
+            __syncthreads();
+            if (kt + 1 >= ntiles_k) break;
+            if (kt + 3 < ntiles_k) load_tile(kt + 3, ra1, rb1);
+            compute(1);
+            if (kt + 2 < ntiles_k) store_tile(0, ra0, rb0);
+            __syncthreads();
+        }
+    } else {   // one stage in registers: fewer VGPRs -> 3 workgroups per CU for the large grids
+        load_tile(0, ra0, rb0);
+        store_tile(0, ra0, rb0);
+        __syncthreads();
+        for (int kt = 0; kt < ntiles_k; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < ntiles_k) load_tile(kt + 1, ra0, rb0);
+            compute(buf);
+            if (kt + 1 < ntiles_k) store_tile(buf ^ 1, ra0, rb0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue -------------------------------------------------------------------------------
@@ -228,10 +252,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         for (int e = 0; e < 8; ++e) bias[e] = (a.bias && col + e < a.NOUT) ? a.bias[col + e] : 0.f;
         const bool full = (col + 8 <= a.NOUT);
 #pragma unroll
-        for (int ps = 0; ps < BM / RP; ++ps) {
+        for (int ps = 0; ps < (BM + RP - 1) / RP; ++ps) {
             const int row = ps * RP + rr;
             const int m = m0 + row;
-            if (m >= a.M) continue;
+            if (row >= BM || m >= a.M) continue;
             float v[8];
             const f32x4 c0 = *reinterpret_cast<const f32x4*>(&sC[row * CLD + cg * 8]);
             const f32x4 c1 = *reinterpret_cast<const f32x4*>(&sC[row * CLD + cg * 8 + 4]);
@@ -286,12 +310,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         }
     }
     if (a.stats && tid < BN && n0 + tid < a.NOUT) {
-        atomicAdd(&a.stats[n0 + tid], sRed[tid]);
-        atomicAdd(&a.stats[a.stats_sq_off + n0 + tid], sRed[BN + tid]);
+        // global float atomics to one address serialise at the memory side: spread the row tiles over replicas
+        float* sp = a.stats + (long)(tm % a.stats_replicas) * a.stats_rep_stride;
+        atomicAdd(&sp[n0 + tid], sRed[tid]);
+        atomicAdd(&sp[a.stats_sq_off + n0 + tid], sRed[BN + tid]);
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH>
 static int launch_conv(const ConvArgs& a0, hipStream_t st) {
     ConvArgs a = a0;
     a.tiles_m = cdiv(a.M, BM);
@@ -304,7 +330,7 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
         set_error("conv: K=%d needs %zu B of LDS (>160 KiB)", a.KTOT, smem);
         return FN_EUNSUPPORTED;
     }
-    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN>;
+    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, DEPTH>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -314,8 +340,8 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
     return check_launch("conv_igemm");
 }
 
-// Tile choice.  BN: smallest padded width, ties -> larger tile.  BM=64 when a 128-row tiling cannot even give
-// one block per CU.
+// Tile choice.  BN: smallest padded width, ties -> larger tile.  BM: the largest of {128, 64, 32} that still gives
+// >= 2 workgroups per CU (these launches are latency-bound: occupancy first), else the smallest (most workgroups).
 static void choose_conv_tile(int M, int NOUT, int& bm, int& bn) {
     bn = 128;
     long best = (long)cdiv(NOUT, 128) * 128;
@@ -323,21 +349,30 @@ static void choose_conv_tile(int M, int NOUT, int& bm, int& bn) {
         const long w = (long)cdiv(NOUT, c) * c;
         if (w < best) { best = w; bn = c; }
     }
-    bm = ((long)cdiv(M, 128) * cdiv(NOUT, bn) < 256) ? 64 : 128;
+    bm = 32;
+    for (int c : {128, 64}) {
+        if ((long)cdiv(M, c) * cdiv(NOUT, bn) >= 512) { bm = c; break; }
+    }
+    // narrow the N tile as well when even 32-row tiles leave most CUs idle
+    while (bm == 32 && bn > 32 && (long)cdiv(M, 32) * cdiv(NOUT, bn) < 384) bn >>= 1;
 }
 
 template <typename T> static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     int bm, bn;
     choose_conv_tile(a.M, a.NOUT, bm, bn);
-    const bool small = bm == 64;
-    if (!small) {
-        if (bn == 128) return launch_conv<T, 128, 128, 2, 2>(a, st);
-        if (bn == 64) return launch_conv<T, 128, 64, 2, 2>(a, st);
-        return launch_conv<T, 128, 32, 4, 1>(a, st);
+    if (bm == 128) {
+        if (bn == 128) return launch_conv<T, 128, 128, 2, 2, 1>(a, st);
+        if (bn == 64) return launch_conv<T, 128, 64, 2, 2, 1>(a, st);
+        return launch_conv<T, 128, 32, 4, 1, 1>(a, st);
     }
-    if (bn == 128) return launch_conv<T, 64, 128, 1, 4>(a, st);
-    if (bn == 64) return launch_conv<T, 64, 64, 2, 2>(a, st);
-    return launch_conv<T, 64, 32, 2, 2>(a, st);
+    if (bm == 64) {
+        if (bn == 128) return launch_conv<T, 64, 128, 1, 4, 1>(a, st);
+        if (bn == 64) return launch_conv<T, 64, 64, 2, 2, 1>(a, st);
+        return launch_conv<T, 64, 32, 2, 2, 1>(a, st);
+    }
+    if (bn == 128) return launch_conv<T, 32, 128, 1, 4, 2>(a, st);
+    if (bn == 64) return launch_conv<T, 32, 64, 1, 4, 2>(a, st);
+    return launch_conv<T, 32, 32, 2, 2, 2>(a, st);
 }
 
 static int check_desc(const fn_conv_desc* d) {
@@ -422,8 +457,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         acol[i] = c0 + (cidx % CGA) * 8;
     }
 
-    u32x4 ra[AP], rb[BP];
-    auto load_tile = [&](int stg) {
+    u32x4 ra0[AP], rb0[BP];
+    auto load_tile = [&](int stg, u32x4 (&ra)[AP], u32x4 (&rb)[BP]) {
         const int mb = mbeg + stg * BK;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
@@ -454,7 +489,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             rb[j] = v;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const u32x4 (&ra)[AP], const u32x4 (&rb)[BP]) {
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int cidx = tid + 256 * i;
@@ -473,18 +508,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
     // transposed-read addressing: lane -> (g, q, p); supplies the address of row rho(g,h,q), columns 4p..4p+3
     const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
     const int rho0 = q + 4 * (g & 1) + 16 * (g >> 1);  // + 8*h + 32*ks
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
-
-    for (int stg = 0; stg < nst; ++stg) {
-        const int buf = stg & 1;
-        if (stg + 1 < nst) load_tile(stg + 1);
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             vec8 fa[MREP], fb[NREP];
@@ -507,7 +535,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
                 for (int j = 0; j < NREP; ++j) acc[i][j] = LP<T>::mfma(fa[i], fb[j], acc[i][j]);
         }
-        if (stg + 1 < nst) store_tile(buf ^ 1);
+    };
+
+    load_tile(0, ra0, rb0);
+    store_tile(0, ra0, rb0);
+    __syncthreads();
+    for (int stg = 0; stg < nst; ++stg) {
+        const int buf = stg & 1;
+        if (stg + 1 < nst) load_tile(stg + 1, ra0, rb0);
+        compute(buf);
+        if (stg + 1 < nst) store_tile(buf ^ 1, ra0, rb0);
         __syncthreads();
     }
 
@@ -574,6 +611,8 @@ extern "C" int fn_conv2d_fwd(const fn_conv_desc* d, void* stream) {
     a.ld_src = d->ld_x; a.ld_out = d->ld_y; a.ld_res = d->ld_res;
     a.relu = d->relu; a.accumulate = d->accumulate; a.out_f32 = d->out_f32; a.scale = d->scale;
     a.stats_sq_off = d->stats_sq_off;
+    a.stats_replicas = d->stats_replicas > 0 ? d->stats_replicas : 1;
+    a.stats_rep_stride = d->stats_rep_stride;
     return d->dtype == FN_BF16 ? dispatch_conv<__bf16>(a, (hipStream_t)stream) : dispatch_conv<_Float16>(a, (hipStream_t)stream);
 }
 

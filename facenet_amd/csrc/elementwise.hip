@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void gather_images_kernel(const uint8_t* __res
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* __restrict__ y, int ld_y, unsigned short* __restrict__ z,
-                                                          int ld_z, int M, int C, const float* __restrict__ stats, int sq_off,
+                                                          int ld_z, int M, int C, const float* __restrict__ stats, int sq_off, int reps, int rep_stride,
                                                           const float* __restrict__ beta, float* __restrict__ save_scale,
                                                           float* __restrict__ save_shift, float* __restrict__ mm, float* __restrict__ mv,
                                                           float momentum, float eps, int relu) {
@@ -110,8 +110,13 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* 
     float* s_shift = sh + C;
     const float invM = 1.f / (float)M;
     for (int c = threadIdx.x; c < C; c += 256) {
-        const float mean = stats[c] * invM;
-        const float var = fmaxf(stats[sq_off + c] * invM - mean * mean, 0.f);
+        float s1 = 0.f, s2v = 0.f;
+        for (int rp = 0; rp < reps; ++rp) {
+            s1 += stats[(long)rp * rep_stride + c];
+            s2v += stats[(long)rp * rep_stride + sq_off + c];
+        }
+        const float mean = s1 * invM;
+        const float var = fmaxf(s2v * invM - mean * mean, 0.f);
         const float rstd = rsqrtf(var + eps);
         const float shf = beta[c] - mean * rstd;
         s_scale[c] = rstd;
@@ -141,35 +146,33 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* 
     }
 }
 
-// pass 1: dbeta[c] += sum dyh, s2[c] += sum dyh*xhat, with zf = y*scale+shift, dyh = dz*(zf>0), xhat = zf - beta
+// pass 1: dbeta[c] += sum dyh, s2[c] += sum dyh*xhat, with zf = y*scale+shift, dyh = dz*(zf>0), xhat = zf - beta.
+// Grid = (row chunks, 64-channel stripes).  Global float atomics to ONE address serialise (~0.09 TB/s, MI355X_MICROARCH
+// "Global float atomics"), so the host bounds row_chunks * 2C to ~64K adds and the stripes supply the parallelism.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const unsigned short* __restrict__ dz, int ld_d,
                                                                  const unsigned short* __restrict__ y, int ld_y, int M, int C,
                                                                  const float* __restrict__ beta, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, float* __restrict__ dbeta,
                                                                  float* __restrict__ s2, int relu, int rows_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float sh[];  // sdb[C], ss2[C]
-    float* sdb = sh;
-    float* ss2 = sh + C;
-    for (int c = threadIdx.x; c < 2 * C; c += 256) sh[c] = 0.f;
-    __syncthreads();
-    const int CG = C >> 3;
-    const int TX = CG > 16 ? 32 : (CG > 8 ? 16 : (CG > 4 ? 8 : 4));
-    const int TY = 256 / TX;
-    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    __shared__ float red[32][2 * 64 + 1];
+    const int c0 = blockIdx.y * 64;
+    const int ncg = min(8, (C - c0) >> 3);          // 16-B channel groups in this stripe
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;   // 8 channel groups x 32 row lanes
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
-    for (int cg = tx; cg < CG; cg += TX) {
-        float b[8], sc[8], sf[8], a1[8], a2[8];
+    float a1[8], a2[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            b[e] = beta[cg * 8 + e]; sc[e] = scale[cg * 8 + e]; sf[e] = shift[cg * 8 + e];
-            a1[e] = 0.f; a2[e] = 0.f;
-        }
-        for (int r = r0 + ty; r < r1; r += TY) {
+    for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+    if (tx < ncg) {
+        const int c = c0 + tx * 8;
+        float b[8], sc[8], sf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { b[e] = beta[c + e]; sc[e] = scale[c + e]; sf[e] = shift[c + e]; }
+        for (int r = r0 + ty; r < r1; r += 32) {
             float g[8], yy[8];
-            unpack8<T>(*reinterpret_cast<const u32x4*>(dz + (long)r * ld_d + cg * 8), g);
-            unpack8<T>(*reinterpret_cast<const u32x4*>(y + (long)r * ld_y + cg * 8), yy);
+            unpack8<T>(*reinterpret_cast<const u32x4*>(dz + (long)r * ld_d + c), g);
+            unpack8<T>(*reinterpret_cast<const u32x4*>(y + (long)r * ld_y + c), yy);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float zf = fmaf(yy[e], sc[e], sf[e]);
@@ -178,16 +181,17 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const unsigned 
                 a2[e] += gg * (zf - b[e]);
             }
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            atomicAdd(&sdb[cg * 8 + e], a1[e]);
-            atomicAdd(&ss2[cg * 8 + e], a2[e]);
-        }
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[ty][tx * 8 + e] = a1[e]; red[ty][64 + tx * 8 + e] = a2[e]; }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        atomicAdd(&dbeta[c], sdb[c]);
-        atomicAdd(&s2[c], ss2[c]);
+    if (threadIdx.x < 128) {
+        const int col = threadIdx.x;   // 0..63 -> dbeta, 64..127 -> s2
+        float s = 0.f;
+#pragma unroll 8
+        for (int t = 0; t < 32; ++t) s += red[t][col];
+        const int c = c0 + (col & 63);
+        if (c < C) atomicAdd(col < 64 ? &dbeta[c] : &s2[c], s);
     }
 }
 
@@ -351,17 +355,15 @@ __global__ __launch_bounds__(256) void residual_bwd_kernel(const unsigned short*
                                                            unsigned short* __restrict__ dtrunk, unsigned short* __restrict__ dup,
                                                            float* __restrict__ dbias, int M, int C, float scale, int relu, int accumulate,
                                                            int rows_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float sh[];  // sdb[C]
-    for (int c = threadIdx.x; c < C; c += 256) sh[c] = 0.f;
-    __syncthreads();
-    const int CG = C >> 3;
-    const int TX = 32, TY = 8;
-    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    __shared__ float red[32][64 + 1];
+    const int c0 = blockIdx.y * 64;
+    const int ncg = min(8, (C - c0) >> 3);
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    for (int cg = tx; cg < CG; cg += TX) {
-        float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int r = r0 + ty; r < r1; r += TY) {
-            const long o = (long)r * C + cg * 8;
+    float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (tx < ncg) {
+        for (int r = r0 + ty; r < r1; r += 32) {
+            const long o = (long)r * C + c0 + tx * 8;
             float g[8], zz[8], u[8];
             unpack8<T>(*reinterpret_cast<const u32x4*>(dout + o), g);
             if (relu) {
@@ -380,11 +382,17 @@ __global__ __launch_bounds__(256) void residual_bwd_kernel(const unsigned short*
             }
             *reinterpret_cast<u32x4*>(dtrunk + o) = pack8<T>(g);
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(&sh[cg * 8 + e], a1[e]);
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = a1[e];
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(&dbias[c], sh[c]);
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int t = 0; t < 32; ++t) s += red[t][threadIdx.x];
+        const int c = c0 + threadIdx.x;
+        if (c < C) atomicAdd(&dbias[c], s);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -472,6 +480,16 @@ template <typename T> __global__ __launch_bounds__(256) void cast_kernel(const f
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = LP<T>::from_f32(x[i]);
 }
 
+// column reductions: row chunks such that chunks * 2C global atomics stay ~<= 64K and every chunk has >= 32 rows
+static inline int reduce_rows_per_block(int M, int C) {
+    int chunks = 32768 / (C > 0 ? C : 1);
+    if (chunks < 8) chunks = 8;
+    if (chunks > 1024) chunks = 1024;
+    int rpb = cdiv(M, chunks);
+    if (rpb < 32) rpb = 32;
+    return rpb;
+}
+
 static inline int grid_for(long work_items, int per_block = 256, int cap = 4096) {
     long g = (work_items + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -517,7 +535,7 @@ extern "C" int fn_gather_images(const uint8_t* pool, const int32_t* idx, uint8_t
 }
 
 extern "C" int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, int M, int C, const float* stats, int stats_sq_off,
-                                    const float* beta,
+                                    int stats_replicas, int stats_rep_stride, const float* beta,
                                     float* save_scale, float* save_shift, float* moving_mean, float* moving_var, float momentum, float eps,
                                     int relu, int dtype, void* stream) {
     DT_CHECK(dtype);
@@ -525,7 +543,7 @@ extern "C" int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, 
                    ld_y >= C && ld_z >= C && C <= 8192, "bn_fwd: bad arguments");
     const int grid = grid_for((long)M * (C / 8), 256, 2048);
     const size_t sm = 2 * C * sizeof(float);
-    LAUNCH_T(dtype, bn_relu_fwd_kernel, dim3(grid), dim3(256), sm, (hipStream_t)stream, (const unsigned short*)y, ld_y, (unsigned short*)z, ld_z, M, C, stats, stats_sq_off, beta, save_scale, save_shift, moving_mean, moving_var, momentum, eps, relu);
+    LAUNCH_T(dtype, bn_relu_fwd_kernel, dim3(grid), dim3(256), sm, (hipStream_t)stream, (const unsigned short*)y, ld_y, (unsigned short*)z, ld_z, M, C, stats, stats_sq_off, stats_replicas > 0 ? stats_replicas : 1, stats_rep_stride, beta, save_scale, save_shift, moving_mean, moving_var, momentum, eps, relu);
     return check_launch("bn_relu_fwd");
 }
 
@@ -535,11 +553,10 @@ extern "C" int fn_bn_relu_train_bwd(void* dz, int ld_d, const void* y, int ld_y,
     FN_REQUIRE(dz && y && beta && save_scale && save_shift && dbeta && s2 && M > 0 && C > 0 && C % 8 == 0 && ld_d % 8 == 0 &&
                    ld_y % 8 == 0 && C <= 4096, "bn_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    int rpb = cdiv(M, 1024);
-    if (rpb < 8) rpb = 8;
-    const int g1 = cdiv(M, rpb);
+    const int rpb = reduce_rows_per_block(M, C);
+    const dim3 g1(cdiv(M, rpb), cdiv(C, 64));
     const int g2 = grid_for((long)M * (C / 8), 256, 2048);
-    LAUNCH_T(dtype, bn_relu_bwd_reduce_kernel, dim3(g1), dim3(256), 2 * C * sizeof(float), st, (const unsigned short*)dz, ld_d, (const unsigned short*)y, ld_y, M, C, beta, save_scale, save_shift, dbeta, s2, relu, rpb);
+    LAUNCH_T(dtype, bn_relu_bwd_reduce_kernel, g1, dim3(256), 0, st, (const unsigned short*)dz, ld_d, (const unsigned short*)y, ld_y, M, C, beta, save_scale, save_shift, dbeta, s2, relu, rpb);
     LAUNCH_T(dtype, bn_relu_bwd_apply_kernel, dim3(g2), dim3(256), 5 * C * sizeof(float), st, (unsigned short*)dz, ld_d, (const unsigned short*)y, ld_y, M, C, beta, save_scale, save_shift, dbeta, s2, relu);
     return check_launch("bn_relu_bwd");
 }
@@ -581,9 +598,8 @@ extern "C" int fn_residual_bwd(const void* dout, const void* out, void* dtrunk, 
                                int accumulate, int dtype, void* stream) {
     DT_CHECK(dtype);
     FN_REQUIRE(dout && dtrunk && dup && dbias && (out || !relu) && M > 0 && C > 0 && C % 8 == 0 && C <= 8192, "residual_bwd: bad arguments");
-    int rpb = cdiv(M, 1024);
-    if (rpb < 8) rpb = 8;
-    LAUNCH_T(dtype, residual_bwd_kernel, dim3(cdiv(M, rpb)), dim3(256), C * sizeof(float), (hipStream_t)stream, (const unsigned short*)dout, (const unsigned short*)out, (unsigned short*)dtrunk, (unsigned short*)dup, dbias, M, C, scale, relu, accumulate, rpb);
+    const int rpb = reduce_rows_per_block(M, C);
+    LAUNCH_T(dtype, residual_bwd_kernel, dim3(cdiv(M, rpb), cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dout, (const unsigned short*)out, (unsigned short*)dtrunk, (unsigned short*)dup, dbias, M, C, scale, relu, accumulate, rpb);
     return check_launch("residual_bwd");
 }
 

@@ -72,6 +72,8 @@ __device__ __forceinline__ unsigned hash_u32(unsigned a, unsigned b, unsigned c)
     return hash_mix(hash_mix(hash_mix(0x9E3779B9u, a), b), c);
 }
 
+// The distance matrix is bitwise symmetric (same products, same order), so thread a reads COLUMN a
+// (dist[j*n + a]: consecutive threads -> consecutive addresses) instead of its own row.
 // Single workgroup; n <= 1024.  scratch (int32, global): per pair q: [a, p, neg, key(u32), cls] at scratch[8 + 5*q].
 // info[0] = #pairs, info[1] = #valid (candidate found), info[2] = 1 if fewer pairs than requested triplets,
 // info[3] = call counter: the effective seed is seed + info[3], so a HIP-graph replay (frozen kernel arguments)
@@ -104,12 +106,12 @@ __global__ __launch_bounds__(1024) void select_triplets_kernel(const float* __re
         int q = s_off[a];
         for (int p = a + 1; p < n; ++p) {
             if (s_lab[p] != s_lab[a]) continue;
-            const float dap = dist[(long)a * n + p];
+            const float dap = dist[(long)p * n + a];
             int c = 0, others = 0;
             for (int j = 0; j < n; ++j) {
                 if (s_lab[j] == s_lab[a]) continue;
                 ++others;
-                const float daj = dist[(long)a * n + j];
+                const float daj = dist[(long)j * n + a];
                 c += ((daj - dap < alpha) && (!semi_hard || daj > dap)) ? 1 : 0;
             }
             int neg = -1, cls = 1;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(1024) void select_triplets_kernel(const float* __re
                 int want = (int)(hash_u32(seed, (unsigned)q, 0u) % (unsigned)c);
                 for (int j = 0; j < n; ++j) {
                     if (s_lab[j] == s_lab[a]) continue;
-                    const float daj = dist[(long)a * n + j];
+                    const float daj = dist[(long)j * n + a];
                     if ((daj - dap < alpha) && (!semi_hard || daj > dap)) {
                         if (want == 0) { neg = j; break; }
                         --want;

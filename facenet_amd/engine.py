@@ -28,10 +28,12 @@ import torch
 
 from . import _lib
 from ._lib import ConvDesc
+from .schedule import Op, Region, region
 
 BN_EPS = 1e-3        # Keras default (inception_resnet_v1.py:57-58 commented out)
 BN_MOMENTUM = 0.99   # Keras default
 L2_WEIGHT = 5e-4     # inception_resnet_v1.py:65
+STAT_REPLICAS = 16   # BN-statistic accumulator replicas (engine-internal)
 
 DEFAULT_CONFIG = {   # inception_resnet_v1.py:13-43
     "reduction_a": {"filters": [[384], [192, 192, 256]]},
@@ -117,14 +119,6 @@ class Rec:
     x: Optional[Slice] = None
     y: Optional[Slice] = None
     extra: dict = field(default_factory=dict)
-
-
-@dataclass
-class Op:
-    name: str
-    fn: Callable
-    args: tuple
-    keep: tuple = ()
 
 
 def _ptr(t: torch.Tensor, elem_off: int = 0) -> int:
@@ -506,6 +500,20 @@ class Lowering:
         return emb.full()
 
     # ---- emission ------------------------------------------------------------------------------
+    # Every launch declares the regions it reads / writes (schedule.Region) so that schedule.Schedule can overlap
+    # independent launches.  Activation regions are channel intervals of an NHWC buffer.
+    @staticmethod
+    def _ra(s: Slice) -> Region:
+        return (s.buf.act.data_ptr(), s.c0, s.c0 + s.C)
+
+    @staticmethod
+    def _rr(s: Slice) -> Region:
+        return (s.buf.raw.data_ptr(), s.c0, s.c0 + s.C)
+
+    @staticmethod
+    def _rg(s: Slice) -> Region:
+        return (s.buf.grad.data_ptr(), s.c0, s.c0 + s.C)
+
     def _desc(self, L: Layer, x: Slice, y: Slice) -> ConvDesc:
         d = ConvDesc()
         d.N, d.H, d.W, d.Cin = self.N, x.buf.H, x.buf.W, L.cin
@@ -516,8 +524,14 @@ class Lowering:
         d.scale = 1.0
         return d
 
-    def _emit(self, lst: List[Op], name: str, fn, *args, keep=()):
-        lst.append(Op(name, fn, args, tuple(keep)))
+    @staticmethod
+    def _replicas(M: int) -> int:
+        """Accumulator replicas for the conv-epilogue BN statistics: thousands of row tiles adding into one address
+        serialise at the memory side (MI355X_MICROARCH.md 'Global float atomics')."""
+        return STAT_REPLICAS if M >= 100000 else (4 if M >= 20000 else 1)
+
+    def _emit(self, lst: List[Op], name: str, fn, *args, keep=(), r=(), w=()):
+        lst.append(Op(name, fn, args, tuple(keep), tuple(r), tuple(w)))
 
     def _grad_mode(self, s: Slice) -> int:
         """0 = first writer of this channel range (overwrite), 1 = accumulate."""
@@ -534,14 +548,16 @@ class Lowering:
         CB = net.CB
         N = self.N
         if self.training:
-            self.ws = torch.zeros(3 * CB, dtype=torch.float32, device=dev)      # sum | sumsq | s2
+            # BN workspace: STAT_REPLICAS x (sum | sumsq) accumulator replicas, then s2 (backward)
+            self.ws = torch.zeros((2 * STAT_REPLICAS + 1) * CB, dtype=torch.float32, device=dev)
             self.save_scale = torch.zeros(CB, dtype=torch.float32, device=dev)
             self.save_shift = torch.zeros(CB, dtype=torch.float32, device=dev)
             self.head_mean = torch.zeros(net.E, dtype=torch.float32, device=dev)
             self.head_rstd = torch.zeros(net.E, dtype=torch.float32, device=dev)
-        f = self.fwd
-        self._emit(f, "image_normalize", lib.fn_image_normalize, _ptr(self.images), _ptr(self.bufs["input"].act), _ptr(self.norm_work),
-                   N, self.images.shape[1] * self.images.shape[2], net.normalization, self.dt)
+        inp = self.bufs["input"]
+        self._emit(self.fwd, "image_normalize", lib.fn_image_normalize, _ptr(self.images), _ptr(inp.act), _ptr(self.norm_work),
+                   N, self.images.shape[1] * self.images.shape[2], net.normalization, self.dt,
+                   r=[region(self.images)], w=[self._ra(inp.full()), region(self.norm_work)])
         for r in self.recs:
             getattr(self, "_fwd_" + r.kind)(r)
 
@@ -551,18 +567,26 @@ class Lowering:
         kind = r.extra["kind"]
         d = self._desc(L, r.x, r.y)
         d.x = _ptr(r.x.buf.act, r.x.c0)
+        reads, writes = [self._ra(r.x)], []
         if self.training:
             d.w = _ptr(net.W_train, L.w_off)
+            reads.append(region(net.W_train, L.w_off, L.w_off + L.numel))
             if kind == "bn":
                 d.y = _ptr(r.y.buf.raw, r.y.c0)
                 d.stats = _ptr(self.ws, L.bn_off)
                 d.stats_sq_off = net.CB
+                d.stats_replicas = self._replicas(r.y.buf.M)
+                d.stats_rep_stride = 2 * net.CB
+                writes += [self._rr(r.y), (self.ws.data_ptr() + 1, L.bn_off, L.bn_off + L.cout)]
         else:
             d.w = _ptr(net.W_infer, L.w_off)
+            reads.append(region(net.W_infer, L.w_off, L.w_off + L.numel))
             if kind == "bn":
                 d.y = _ptr(r.y.buf.act, r.y.c0)
                 d.bias = _ptr(net.fold_bias, L.bn_off)
                 d.relu = 1
+                reads.append(region(net.fold_bias, L.bn_off, L.bn_off + L.cout))
+                writes.append(self._ra(r.y))
         if kind == "resid":
             t: Slice = r.extra["trunk"]
             d.y = _ptr(r.y.buf.act, r.y.c0)
@@ -571,16 +595,20 @@ class Lowering:
             d.ld_res = t.buf.C
             d.scale = r.extra["scale"]
             d.relu = 1 if r.extra["relu"] else 0
+            reads += [self._ra(t), region(net.P, L.bias_off, L.bias_off + L.cout)]
+            writes.append(self._ra(r.y))
         elif kind == "f32":
             tgt = r.y.buf
             if L.has_bn and not self.training:       # inference: BN folded, write the embedding buffer directly
                 tgt = self.bufs["features/bn"]
                 d.bias = _ptr(net.fold_bias, L.bn_off)
+                reads.append(region(net.fold_bias, L.bn_off, L.bn_off + L.cout))
             d.y = _ptr(tgt.act, r.y.c0)
             d.out_f32 = 1
             if L.has_bias:
                 d.bias = _ptr(net.P, L.bias_off)
-        self._emit(self.fwd, "conv_fwd:" + L.name, lib.fn_conv2d_fwd, C.byref(d), keep=(d,))
+            writes.append((tgt.act.data_ptr(), r.y.c0, r.y.c0 + r.y.C))
+        self._emit(self.fwd, "conv_fwd:" + L.name, lib.fn_conv2d_fwd, C.byref(d), keep=(d,), r=reads, w=writes)
 
     def _fwd_bn(self, r: Rec):
         if not self.training:
@@ -589,28 +617,33 @@ class Lowering:
         b, c0, Cc = r.y.buf, r.y.c0, r.y.C
         o = b.bn_off + c0
         self._emit(self.fwd, "bn_relu_fwd:" + b.name, lib.fn_bn_relu_train_fwd, _ptr(b.raw, c0), b.C, _ptr(b.act, c0), b.C, b.M, Cc,
-                   _ptr(self.ws, o), net.CB, _ptr(net.P, net.beta_base + o), _ptr(self.save_scale, o), _ptr(self.save_shift, o),
-                   _ptr(net.S_mean, o), _ptr(net.S_var, o), BN_MOMENTUM, BN_EPS, 1 if r.extra["relu"] else 0, self.dt)
+                   _ptr(self.ws, o), net.CB, self._replicas(b.M), 2 * net.CB, _ptr(net.P, net.beta_base + o), _ptr(self.save_scale, o),
+                   _ptr(self.save_shift, o), _ptr(net.S_mean, o), _ptr(net.S_var, o), BN_MOMENTUM, BN_EPS, 1 if r.extra["relu"] else 0, self.dt,
+                   r=[self._rr(r.y), (self.ws.data_ptr() + 1, o, o + Cc), region(net.P, net.beta_base + o, net.beta_base + o + Cc)],
+                   w=[self._ra(r.y), region(self.save_scale, o, o + Cc), region(self.save_shift, o, o + Cc),
+                      region(net.S_mean, o, o + Cc), region(net.S_var, o, o + Cc)])
 
     def _fwd_maxpool(self, r: Rec):
         x, y = r.x, r.y
         self._emit(self.fwd, "maxpool_fwd", self.net.lib.fn_maxpool3x3s2_fwd, _ptr(x.buf.act, x.c0), x.buf.C, _ptr(y.buf.act, y.c0), y.buf.C,
-                   self.N, x.buf.H, x.buf.W, x.C, self.dt)
+                   self.N, x.buf.H, x.buf.W, x.C, self.dt, r=[self._ra(x)], w=[self._ra(y)])
 
     def _fwd_avgpool(self, r: Rec):
         x, y = r.x, r.y
-        self._emit(self.fwd, "avgpool_fwd", self.net.lib.fn_avgpool_fwd, _ptr(x.buf.act), _ptr(y.buf.act), self.N, x.buf.H * x.buf.W, x.C, self.dt)
+        self._emit(self.fwd, "avgpool_fwd", self.net.lib.fn_avgpool_fwd, _ptr(x.buf.act), _ptr(y.buf.act), self.N, x.buf.H * x.buf.W, x.C, self.dt,
+                   r=[self._ra(x)], w=[self._ra(y)])
 
     def _fwd_head_bn(self, r: Rec):
         if not self.training:
             return  # folded into the Dense epilogue
         net, L = self.net, r.layer
         o = L.bn_off
-        tr = 1 if self.training else 0
-        sm = _ptr(self.head_mean) if self.training else None
-        sr = _ptr(self.head_rstd) if self.training else None
         self._emit(self.fwd, "head_bn_fwd", net.lib.fn_head_bn_fwd, _ptr(r.x.buf.act), _ptr(r.y.buf.act), self.N, net.E,
-                   _ptr(net.P, net.beta_base + o), _ptr(net.S_mean, o), _ptr(net.S_var, o), sm, sr, tr, BN_MOMENTUM, BN_EPS)
+                   _ptr(net.P, net.beta_base + o), _ptr(net.S_mean, o), _ptr(net.S_var, o), _ptr(self.head_mean), _ptr(self.head_rstd), 1,
+                   BN_MOMENTUM, BN_EPS,
+                   r=[self._ra(r.x), region(net.P, net.beta_base + o, net.beta_base + o + net.E)],
+                   w=[self._ra(r.y), region(self.head_mean), region(self.head_rstd), region(net.S_mean, o, o + net.E),
+                      region(net.S_var, o, o + net.E)])
 
     # ---- backward (training plans only); demb = fp32 gradient wrt the un-normalised embedding ----
     def build_backward(self, demb: torch.Tensor):
@@ -618,6 +651,7 @@ class Lowering:
         for b in self.bufs.values():
             b.grad_ranges = []
         self._demb = demb
+        self._dup: Dict[str, torch.Tensor] = {}
         for r in reversed(self.recs):
             getattr(self, "_bwd_" + r.kind)(r)
 
@@ -626,10 +660,12 @@ class Lowering:
 
     def _bwd_head_bn(self, r: Rec):
         net, L = self.net, r.layer
-        # dy (low precision) lands in the grad buffer of the fp32 logits buffer's low-precision shadow
         self.head_dy = torch.zeros(self.N, net.E, dtype=self.dtype, device=net.device)
+        gb = net.beta_base + L.bn_off
         self._emit(self.bwd, "head_bn_bwd", net.lib.fn_head_bn_bwd, _ptr(self._demb), _ptr(r.x.buf.act), _ptr(self.head_mean),
-                   _ptr(self.head_rstd), _ptr(net.G, net.beta_base + L.bn_off), _ptr(self.head_dy), self.N, net.E, self.dt)
+                   _ptr(self.head_rstd), _ptr(net.G, gb), _ptr(self.head_dy), self.N, net.E, self.dt,
+                   r=[region(self._demb), self._ra(r.x), region(self.head_mean), region(self.head_rstd)],
+                   w=[region(self.head_dy), region(net.G, gb, gb + net.E)])
 
     def _bwd_conv(self, r: Rec):
         net, lib, L = self.net, self.net.lib, r.layer
@@ -637,24 +673,26 @@ class Lowering:
         x, y = r.x, r.y
         if kind == "resid":
             t: Slice = r.extra["trunk"]
-            if not hasattr(self, "_dup") or self._dup.get((y.buf.M, y.buf.C)) is None:
-                self._dup = getattr(self, "_dup", {})
-                self._dup[(y.buf.M, y.buf.C)] = torch.zeros(y.buf.M, y.buf.C, dtype=self.dtype, device=net.device)
-            dup = self._dup[(y.buf.M, y.buf.C)]
+            # one scratch per block: the weight gradient of this block may still be reading it while the next block's
+            # residual backward runs on another stream
+            dup = torch.zeros(y.buf.M, y.buf.C, dtype=self.dtype, device=net.device)
+            self._dup[L.name] = dup
             acc = self._grad_mode(t)
             self._emit(self.bwd, "residual_bwd:" + L.name, lib.fn_residual_bwd, _ptr(y.buf.grad), _ptr(y.buf.act), _ptr(t.buf.grad),
-                       _ptr(dup), _ptr(net.G, L.bias_off), y.buf.M, y.buf.C, r.extra["scale"], 1 if r.extra["relu"] else 0, acc, self.dt)
-            dy_ptr, ld_dy = _ptr(dup), y.buf.C
+                       _ptr(dup), _ptr(net.G, L.bias_off), y.buf.M, y.buf.C, r.extra["scale"], 1 if r.extra["relu"] else 0, acc, self.dt,
+                       r=[self._rg(y), self._ra(y)], w=[self._rg(t), region(dup), region(net.G, L.bias_off, L.bias_off + L.cout)])
+            dy_ptr, ld_dy, dy_reg = _ptr(dup), y.buf.C, region(dup)
         elif kind == "f32":
-            dy_ptr, ld_dy = _ptr(self.head_dy), net.E
+            dy_ptr, ld_dy, dy_reg = _ptr(self.head_dy), net.E, region(self.head_dy)
         else:
-            dy_ptr, ld_dy = _ptr(y.buf.grad, y.c0), y.buf.C
+            dy_ptr, ld_dy, dy_reg = _ptr(y.buf.grad, y.c0), y.buf.C, self._rg(y)
         d = self._desc(L, x, y)
         d.ld_y = ld_dy
         d.x = _ptr(x.buf.act, x.c0)
         d.y = dy_ptr
         d.dw = _ptr(net.G, L.w_off)
-        self._emit(self.bwd, "conv_wgrad:" + L.name, lib.fn_conv2d_wgrad, C.byref(d), keep=(d,))
+        self._emit(self.bwd, "conv_wgrad:" + L.name, lib.fn_conv2d_wgrad, C.byref(d), keep=(d,),
+                   r=[self._ra(x), dy_reg], w=[region(net.G, L.w_off, L.w_off + L.numel)])
         if x.buf.name != "input":
             g = self._desc(L, x, y)
             g.ld_y = ld_dy
@@ -662,16 +700,20 @@ class Lowering:
             g.w = _ptr(net.Wt_train, L.w_off)
             g.dx = _ptr(x.buf.grad, x.c0)
             g.accumulate = self._grad_mode(x)
-            self._emit(self.bwd, "conv_dgrad:" + L.name, lib.fn_conv2d_dgrad, C.byref(g), keep=(g,))
+            self._emit(self.bwd, "conv_dgrad:" + L.name, lib.fn_conv2d_dgrad, C.byref(g), keep=(g,),
+                       r=[dy_reg, region(net.Wt_train, L.w_off, L.w_off + L.numel)], w=[self._rg(x)])
         self._mark(L)
 
     def _bwd_bn(self, r: Rec):
         net = self.net
         b, c0, Cc = r.y.buf, r.y.c0, r.y.C
         o = b.bn_off + c0
+        gb = net.beta_base + o
         self._emit(self.bwd, "bn_relu_bwd:" + b.name, net.lib.fn_bn_relu_train_bwd, _ptr(b.grad, c0), b.C, _ptr(b.raw, c0), b.C, b.M, Cc,
-                   _ptr(net.P, net.beta_base + o), _ptr(self.save_scale, o), _ptr(self.save_shift, o), _ptr(net.G, net.beta_base + o),
-                   _ptr(self.ws, 2 * net.CB + o), 1 if r.extra["relu"] else 0, self.dt)
+                   _ptr(net.P, gb), _ptr(self.save_scale, o), _ptr(self.save_shift, o), _ptr(net.G, gb),
+                   _ptr(self.ws, 2 * STAT_REPLICAS * net.CB + o), 1 if r.extra["relu"] else 0, self.dt,
+                   r=[self._rr(r.y), region(net.P, gb, gb + Cc), region(self.save_scale, o, o + Cc), region(self.save_shift, o, o + Cc)],
+                   w=[self._rg(r.y), region(net.G, gb, gb + Cc), (self.ws.data_ptr() + 2, o, o + Cc)])
 
     def _bwd_maxpool(self, r: Rec):
         x, y = r.x, r.y
@@ -679,17 +721,23 @@ class Lowering:
             return
         acc = self._grad_mode(x)
         self._emit(self.bwd, "maxpool_bwd", self.net.lib.fn_maxpool3x3s2_bwd, _ptr(x.buf.act, x.c0), x.buf.C, _ptr(y.buf.grad, y.c0), y.buf.C,
-                   _ptr(x.buf.grad, x.c0), x.buf.C, self.N, x.buf.H, x.buf.W, x.C, acc, self.dt)
+                   _ptr(x.buf.grad, x.c0), x.buf.C, self.N, x.buf.H, x.buf.W, x.C, acc, self.dt,
+                   r=[self._ra(x), self._rg(y)], w=[self._rg(x)])
 
     def _bwd_avgpool(self, r: Rec):
         x, y = r.x, r.y
         assert self._grad_mode(x) == 0
-        self._emit(self.bwd, "avgpool_bwd", self.net.lib.fn_avgpool_bwd, _ptr(y.buf.grad), _ptr(x.buf.grad), self.N, x.buf.H * x.buf.W, x.C, self.dt)
+        self._emit(self.bwd, "avgpool_bwd", self.net.lib.fn_avgpool_bwd, _ptr(y.buf.grad), _ptr(x.buf.grad), self.N, x.buf.H * x.buf.W, x.C, self.dt,
+                   r=[self._rg(y)], w=[self._rg(x)])
 
     # ---- execution -----------------------------------------------------------------------------
     @staticmethod
     def run_ops(ops: Sequence[Op], stream: int, lo: int = 0, hi: Optional[int] = None):
+        """Single-stream, program-order replay (reference semantics for the scheduled replay)."""
         for op in ops[lo:hi]:
+            if getattr(op.fn, "_torch_op", False):
+                op.fn(*op.args)
+                continue
             rc = op.fn(*op.args, stream)
             if rc:
                 _lib.check(rc, op.name)

@@ -19,11 +19,12 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from .engine import BN_EPS, L2_WEIGHT, Lowering, Network, Op, _pad8, _ptr
+from .engine import BN_EPS, L2_WEIGHT, Lowering, Network, _pad8, _ptr
+from .schedule import Op, Schedule, StreamSet, make_events, region, run_schedule, torch_op
 
 
 class GraphRunner:
-    """Capture a launch list into HIP graphs (one per segment) and replay them.
+    """Capture launch schedules into HIP graphs (one per segment) and replay them.
 
     Segments exist so that collectives issued between them stay outside the captured graphs."""
 
@@ -32,20 +33,28 @@ class GraphRunner:
         self.graphs: List[torch.cuda.CUDAGraph] = []
         self.pool = None
 
-    def capture(self, fn: Callable[[int], None]) -> torch.cuda.CUDAGraph:
+    def capture(self, fn: Callable[[], None]) -> torch.cuda.CUDAGraph:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=self.pool):
-            fn(torch.cuda.current_stream(self.device).cuda_stream)
+            fn()
         if self.pool is None:
             self.pool = g.pool()
         self.graphs.append(g)
         return g
 
 
+def _streams_for(net: Network, n_streams: int) -> StreamSet:
+    ss = getattr(net, "_stream_set", None)
+    if ss is None or len(ss.side) < n_streams - 1:
+        ss = StreamSet(net.device, n_streams)
+        net._stream_set = ss
+    return ss
+
+
 class Trainer:
     def __init__(self, net: Network, batch: int, loss: str = "triplet", alpha: float = 0.2, lr: float = 0.05, beta1: float = 0.9,
                  beta2: float = 0.999, epsilon: float = 0.1, l2: float = L2_WEIGHT, world_size: int = 1, process_group=None,
-                 n_buckets: int = 6):
+                 n_buckets: int = 6, n_streams: int = 2):
         if loss not in ("triplet", "softmax"):
             raise ValueError(f"unknown loss {loss!r}")
         if loss == "triplet" and batch % 3:
@@ -55,6 +64,7 @@ class Trainer:
         self.net, self.N, self.loss_kind, self.alpha = net, batch, loss, alpha
         self.beta1, self.beta2, self.eps, self.l2 = beta1, beta2, epsilon, l2
         self.world, self.pg = world_size, process_group
+        self.n_streams = n_streams
         dev, E, lib = net.device, net.E, net.lib
         self.lib = lib
         if net.G is None:
@@ -68,17 +78,25 @@ class Trainer:
         self.plan: Lowering = net.plan(batch, training=True)
         self.demb = torch.zeros(batch, E, dtype=torch.float32, device=dev)
         self.dt = _lib.dtype_code(net.train_dtype)
-        emb = self.plan.embedding.buf.act
+        ebuf = self.plan.embedding.buf
+        emb = ebuf.act
+        r_emb = region(emb)
         self.emb = emb.view(batch, E)
+        self.pre_ops: List[Op] = [
+            Op("zero_grads", torch_op(lambda: self.G.zero_()), (), writes=(region(self.G),)),
+            Op("zero_bn_workspace", torch_op(lambda: self.plan.ws.zero_()), (),
+               writes=(region(self.plan.ws), (self.plan.ws.data_ptr() + 1, 0, net.CB), (self.plan.ws.data_ptr() + 2, 0, net.CB))),
+        ]
         self.loss_ops: List[Op] = []
-        self.post_bwd_ops: List[Op] = []
         if loss == "triplet":
             self.embn = torch.zeros(batch, E, dtype=torch.float32, device=dev)
             self.dembn = torch.zeros(batch, E, dtype=torch.float32, device=dev)
-            self._op(self.loss_ops, "l2norm_fwd", lib.fn_l2norm_fwd, _ptr(emb), _ptr(self.embn), batch, E, 1e-10)
+            self._op(self.loss_ops, "l2norm_fwd", lib.fn_l2norm_fwd, _ptr(emb), _ptr(self.embn), batch, E, 1e-10,
+                     r=[r_emb], w=[region(self.embn)])
             self._op(self.loss_ops, "triplet_loss", lib.fn_triplet_loss_fwd_bwd, _ptr(self.embn), _ptr(self.dembn), _ptr(self.loss),
-                     batch // 3, E, alpha)
-            self._op(self.loss_ops, "l2norm_bwd", lib.fn_l2norm_bwd, _ptr(emb), _ptr(self.dembn), _ptr(self.demb), batch, E, 1e-10)
+                     batch // 3, E, alpha, r=[region(self.embn)], w=[region(self.dembn), region(self.loss)])
+            self._op(self.loss_ops, "l2norm_bwd", lib.fn_l2norm_bwd, _ptr(emb), _ptr(self.dembn), _ptr(self.demb), batch, E, 1e-10,
+                     r=[r_emb, region(self.dembn)], w=[region(self.demb)])
         else:
             L = net.layers["classifier/logits"]
             Cp, Cr = L.cout, L.cout_real
@@ -86,31 +104,43 @@ class Trainer:
             self.emb_lp = torch.zeros(batch, E, dtype=net.train_dtype, device=dev)
             self.logits = torch.zeros(batch, Cp, dtype=torch.float32, device=dev)
             self.dlogits = torch.zeros(batch, Cp, dtype=net.train_dtype, device=dev)
+            rw = region(net.W_train, L.w_off, L.w_off + L.numel)
+            rwt = region(net.Wt_train, L.w_off, L.w_off + L.numel)
+            rgw = region(self.G, L.w_off, L.w_off + L.numel)
+            rgb = region(self.G, L.bias_off, L.bias_off + L.cout)
             d = self._cls_desc(L)
             d.x, d.w, d.y, d.bias, d.out_f32 = _ptr(self.emb_lp), _ptr(net.W_train, L.w_off), _ptr(self.logits), _ptr(net.P, L.bias_off), 1
-            self._op(self.loss_ops, "cast_emb", lib.fn_cast_f32_to_lp, _ptr(emb), _ptr(self.emb_lp), batch * E, self.dt)
-            self._op(self.loss_ops, "conv_fwd:classifier", lib.fn_conv2d_fwd, C.byref(d), keep=(d,))
+            self._op(self.loss_ops, "cast_emb", lib.fn_cast_f32_to_lp, _ptr(emb), _ptr(self.emb_lp), batch * E, self.dt,
+                     r=[r_emb], w=[region(self.emb_lp)])
+            self._op(self.loss_ops, "conv_fwd:classifier", lib.fn_conv2d_fwd, C.byref(d), keep=(d,),
+                     r=[region(self.emb_lp), rw, region(net.P, L.bias_off, L.bias_off + L.cout)], w=[region(self.logits)])
             self._op(self.loss_ops, "softmax_xent", lib.fn_softmax_xent_fwd_bwd, _ptr(self.logits), Cp, _ptr(self.labels), _ptr(self.loss),
-                     _ptr(self.dlogits), Cp, _ptr(self.G, L.bias_off), batch, Cr, 1.0 / batch, self.dt)
+                     _ptr(self.dlogits), Cp, _ptr(self.G, L.bias_off), batch, Cr, 1.0 / batch, self.dt,
+                     r=[region(self.logits), region(self.labels)], w=[region(self.loss), region(self.dlogits), rgb])
             w = self._cls_desc(L)
             w.x, w.y, w.dw = _ptr(self.emb_lp), _ptr(self.dlogits), _ptr(self.G, L.w_off)
-            self._op(self.loss_ops, "conv_wgrad:classifier", lib.fn_conv2d_wgrad, C.byref(w), keep=(w,))
+            self._op(self.loss_ops, "conv_wgrad:classifier", lib.fn_conv2d_wgrad, C.byref(w), keep=(w,),
+                     r=[region(self.emb_lp), region(self.dlogits)], w=[rgw])
             g = self._cls_desc(L)
             g.y, g.w, g.dx, g.out_f32 = _ptr(self.dlogits), _ptr(net.Wt_train, L.w_off), _ptr(self.demb), 1
-            self._op(self.loss_ops, "conv_dgrad:classifier", lib.fn_conv2d_dgrad, C.byref(g), keep=(g,))
+            self._op(self.loss_ops, "conv_dgrad:classifier", lib.fn_conv2d_dgrad, C.byref(g), keep=(g,),
+                     r=[region(self.dlogits), rwt], w=[region(self.demb)])
         self.plan.build_backward(self.demb)
         self.opt_ops: List[Op] = []
-        self._op(self.opt_ops, "adam_tick", lib.fn_adam_tick, _ptr(self.hyper), beta1, beta2)
+        self._op(self.opt_ops, "adam_tick", lib.fn_adam_tick, _ptr(self.hyper), beta1, beta2, w=[region(self.hyper)])
         self._op(self.opt_ops, "adam_keras", lib.fn_adam_keras, _ptr(net.P), _ptr(self.G), _ptr(self.M), _ptr(self.V), _ptr(net.W_train),
-                 net.n_kernel, net.n_params, net.n_decay, _ptr(self.hyper), beta1, beta2, epsilon, l2, self.dt)
+                 net.n_kernel, net.n_params, net.n_decay, _ptr(self.hyper), beta1, beta2, epsilon, l2, self.dt,
+                 r=[region(self.G), region(self.hyper)], w=[region(net.P), region(self.M), region(self.V), region(net.W_train)])
         self._op(self.opt_ops, "pack_transpose", lib.fn_pack_transpose, _ptr(net.W_train), _ptr(net.Wt_train), _ptr(net.table),
-                 len(net.layers), net.max_layer_elems, self.dt)
+                 len(net.layers), net.max_layer_elems, self.dt, r=[region(net.W_train)], w=[region(net.Wt_train)])
         self.buckets = self._make_buckets(n_buckets) if world_size > 1 else []
         self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
+        self.streams = _streams_for(net, n_streams)
+        self._build_segments()
         self._graph = None
 
-    def _op(self, lst, name, fn, *args, keep=()):
-        lst.append(Op(name, fn, args, tuple(keep)))
+    def _op(self, lst, name, fn, *args, keep=(), r=(), w=()):
+        lst.append(Op(name, fn, args, tuple(keep), tuple(r), tuple(w)))
 
     def _cls_desc(self, L):
         d = _lib.ConvDesc()
@@ -150,94 +180,77 @@ class Trainer:
         import torch.distributed as dist
         dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
 
+    def _build_segments(self):
+        """world 1: one schedule for the whole step.  world > 1: the backward is cut where a gradient bucket becomes
+        complete; every segment is its own multi-stream schedule (all streams joined at its end), and the bucket's
+        all-reduce is issued on the communication stream while the next segment computes."""
+        head = self.pre_ops + self.plan.fwd + self.loss_ops
+        self.segments: List[Tuple[Optional[Schedule], Optional[Tuple[int, int]]]] = []
+        if self.world == 1:
+            self.segments.append((Schedule(head + self.plan.bwd + self.opt_ops, self.n_streams), None))
+            return
+        pos, first = 0, True
+        for (ready, lo, hi) in self.buckets:
+            a, b = pos, max(pos, ready)
+            ops = (head if first else []) + self.plan.bwd[a:b]
+            self.segments.append((Schedule(ops, self.n_streams) if ops else None, (lo, hi)))
+            pos, first = b, False
+        assert pos == len(self.plan.bwd)
+        self.segments.append((Schedule(self.opt_ops, 1), None))
+
     # ---- one step ------------------------------------------------------------------------------
     def _zero(self):
         self.G.zero_()
         self.plan.ws.zero_()
 
-    def _run_compute(self, stream: int, lo: int, hi: int):
-        Lowering.run_ops(self.plan.bwd, stream, lo, hi)
-
-    def step_eager(self):
-        """zero -> forward -> loss -> backward (+ bucketed all-reduce) -> Adam; returns nothing (loss stays on device)."""
-        net = self.net
-        st = net.stream()
-        self._zero()
-        Lowering.run_ops(self.plan.fwd, st)
-        Lowering.run_ops(self.loss_ops, st)
+    def _run_segments(self, launch: Callable[[int], None]):
         if self.world == 1:
-            Lowering.run_ops(self.plan.bwd, st)
-        else:
-            cur = torch.cuda.current_stream(net.device)
-            pos = 0
-            for (ready, lo, hi) in self.buckets:
-                if ready > pos:
-                    Lowering.run_ops(self.plan.bwd, st, pos, ready)
-                    pos = ready
-                ev = torch.cuda.Event()
-                ev.record(cur)
-                self.comm_stream.wait_event(ev)
-                with torch.cuda.stream(self.comm_stream):
-                    self._allreduce(lo, hi)
-            if pos < len(self.plan.bwd):
-                Lowering.run_ops(self.plan.bwd, st, pos, None)
-            cur.wait_stream(self.comm_stream)
-        Lowering.run_ops(self.opt_ops, st)
-
-    def capture(self):
-        """Capture the step into HIP graph(s).  With world_size > 1 the backward is cut at bucket boundaries and
-        the all-reduces are issued between graph launches on the communication stream."""
-        net = self.net
-        self.step_eager()           # warm-up: first-call attribute set-up, allocator
-        torch.cuda.synchronize(net.device)
-        runner = GraphRunner(net.device)
-        segs: List[Tuple[torch.cuda.CUDAGraph, Optional[Tuple[int, int]]]] = []
-        if self.world == 1:
-            def whole(st):
-                self._zero()
-                Lowering.run_ops(self.plan.fwd, st)
-                Lowering.run_ops(self.loss_ops, st)
-                Lowering.run_ops(self.plan.bwd, st)
-                Lowering.run_ops(self.opt_ops, st)
-            segs.append((runner.capture(whole), None))
-        else:
-            pos = 0
-            first = True
-            for (ready, lo, hi) in self.buckets:
-                a, b = pos, max(pos, ready)
-
-                def seg(st, a=a, b=b, first=first):
-                    if first:
-                        self._zero()
-                        Lowering.run_ops(self.plan.fwd, st)
-                        Lowering.run_ops(self.loss_ops, st)
-                    Lowering.run_ops(self.plan.bwd, st, a, b)
-                if first or b > a:
-                    segs.append((runner.capture(seg), (lo, hi)))
-                else:
-                    segs.append((None, (lo, hi)))
-                pos, first = b, False
-            segs.append((runner.capture(lambda st: Lowering.run_ops(self.opt_ops, st)), None))
-        self._graph = (runner, segs)
-
-    def step(self):
-        if self._graph is None:
-            return self.step_eager()
-        _, segs = self._graph
-        if self.world == 1:
-            segs[0][0].replay()
+            launch(0)
             return
         cur = torch.cuda.current_stream(self.net.device)
-        for g, rng in segs[:-1]:
-            if g is not None:
-                g.replay()
+        for i, (sched, rng) in enumerate(self.segments[:-1]):
+            if sched is not None:
+                launch(i)
             ev = torch.cuda.Event()
             ev.record(cur)
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
                 self._allreduce(*rng)
         cur.wait_stream(self.comm_stream)
-        segs[-1][0].replay()
+        launch(len(self.segments) - 1)
+
+    def step_eager(self):
+        """zero -> forward -> loss -> backward (+ bucketed all-reduce) -> Adam; the loss stays on device."""
+        self._run_segments(lambda i: run_schedule(self.segments[i][0], self.streams))
+
+    def capture(self):
+        """Capture every segment into a HIP graph (multi-stream edges become graph dependencies); with world_size > 1
+        the all-reduces are issued between graph launches on the communication stream.
+
+        ROCm 7.0/7.2 note (measured on MI355X): ending a capture whose fork/join pattern spans 3 or more streams
+        segfaults inside hipStreamEndCapture, while 2 streams capture and replay correctly -- schedules wider than 2
+        streams are therefore re-placed on 2 streams for the captured path (eager replay keeps the requested width)."""
+        if self.n_streams > 2:
+            self.n_streams = 2
+            self._build_segments()
+        self.step_eager()           # warm-up: first-call attribute set-up, allocator
+        torch.cuda.synchronize(self.net.device)
+        runner = GraphRunner(self.net.device)
+        graphs, keep = [], []
+        for (sched, _) in self.segments:
+            if sched is None:
+                graphs.append(None)
+                continue
+            evs = make_events(sched)     # events owned by this capture only
+            keep.append(evs)
+            graphs.append(runner.capture(lambda sched=sched, evs=evs: run_schedule(sched, self.streams, evs)))
+        self._graph = (runner, graphs, keep)
+
+    def step(self):
+        if self._graph is None:
+            return self.step_eager()
+        graphs = self._graph[1]
+        self._run_segments(lambda i: graphs[i].replay())
 
     # ---- host conveniences -----------------------------------------------------------------------
     def set_images(self, images: torch.Tensor, labels: Optional[torch.Tensor] = None):
@@ -256,9 +269,10 @@ class TripletMiner:
     """Embeds a PxK pool with the inference path, selects triplets on device and assembles the train batch."""
 
     def __init__(self, net: Network, pool_size: int, labels: Sequence[int], nrof_triplets: int, alpha: float = 0.2, seed: int = 0,
-                 semi_hard: bool = False):
+                 semi_hard: bool = False, n_streams: int = 2):
         self.net, self.n, self.T, self.alpha, self.seed, self.semi_hard = net, pool_size, nrof_triplets, alpha, seed, semi_hard
-        dev, lib = net.device, net.lib
+        dev = net.device
+        self.n_streams = n_streams
         self.plan = net.plan(pool_size, training=False)
         E = net.E
         self.emb = self.plan.embedding.buf.act.view(pool_size, E)
@@ -269,20 +283,28 @@ class TripletMiner:
         qmax = pool_size * (pool_size - 1) // 2
         self.info = torch.zeros(8 + 5 * qmax, dtype=torch.int32, device=dev)
         self.ops: List[Op] = []
+        self.sched: Optional[Schedule] = None
+        self.streams = _streams_for(net, n_streams)
 
     def build(self, train_images: torch.Tensor):
         """train_images: the uint8 [3T,H,W,3] input buffer of the training plan (filled by the gather)."""
         net, lib, n, E = self.net, self.net.lib, self.n, self.net.E
         o = self.ops
         bytes_per = train_images[0].numel()
-        o.append(Op("fold_bn", lambda st: (net.refresh_folded(st), 0)[1], ()))
+        o.append(Op("fold_bn", lambda st: (net.refresh_folded(st), 0)[1], (),
+                    reads=(region(net.P), region(net.S_mean), region(net.S_var)), writes=(region(net.W_infer), region(net.fold_bias))))
         o.extend(self.plan.fwd)
-        o.append(Op("l2norm_fwd", lib.fn_l2norm_fwd, (_ptr(self.emb), _ptr(self.embn), n, E, 1e-10)))
-        o.append(Op("pairwise_sqdist", lib.fn_pairwise_sqdist, (_ptr(self.embn), _ptr(self.embn), _ptr(self.dist), None, n, n, E, 2)))
+        o.append(Op("l2norm_fwd", lib.fn_l2norm_fwd, (_ptr(self.emb), _ptr(self.embn), n, E, 1e-10),
+                    reads=(region(self.plan.embedding.buf.act),), writes=(region(self.embn),)))
+        o.append(Op("pairwise_sqdist", lib.fn_pairwise_sqdist, (_ptr(self.embn), _ptr(self.embn), _ptr(self.dist), None, n, n, E, 2),
+                    reads=(region(self.embn),), writes=(region(self.dist),)))
         o.append(Op("select_triplets", lib.fn_select_triplets, (_ptr(self.dist), _ptr(self.labels), n, self.alpha, self.T, self.seed,
-                                                                 1 if self.semi_hard else 0, _ptr(self.triplets), _ptr(self.info))))
+                                                                 1 if self.semi_hard else 0, _ptr(self.triplets), _ptr(self.info)),
+                    reads=(region(self.dist), region(self.labels)), writes=(region(self.triplets), region(self.info))))
         o.append(Op("gather_images", lib.fn_gather_images, (_ptr(self.plan.images), _ptr(self.triplets), _ptr(train_images), 3 * self.T,
-                                                             bytes_per)))
+                                                             bytes_per),
+                    reads=(region(self.plan.images), region(self.triplets)), writes=(region(train_images),)))
+        self.sched = Schedule(o, self.n_streams)
 
-    def run(self, stream: Optional[int] = None):
-        Lowering.run_ops(self.ops, self.net.stream() if stream is None else stream)
+    def run(self, events=None):
+        run_schedule(self.sched, self.streams, events)

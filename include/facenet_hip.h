@@ -46,6 +46,8 @@ typedef struct fn_conv_desc {
     float scale;               /* fwd: y = resid + scale*(conv + bias) when resid != NULL, else conv + bias */
     int32_t splits;            /* wgrad: split-K factor over pixels (0 = library picks) */
     int32_t stats_sq_off;      /* fwd: element offset from the sum array to the sum-of-squares array in `stats` */
+    int32_t stats_replicas;    /* fwd: number of accumulator replicas (row tile t adds into replica t % replicas); 0/1 = one */
+    int32_t stats_rep_stride;  /* fwd: element stride between replicas */
     const void* x;             /* fwd/wgrad: input activations; dgrad: unused */
     const void* w;             /* fwd: packed [Cout][KH*KW*Cin]; dgrad: transposed pack [Cin][KH*KW*Cout] */
     void* y;                   /* fwd: output; dgrad/wgrad: dY (read) */
@@ -75,7 +77,8 @@ int fn_gather_images(const uint8_t* pool, const int32_t* idx, uint8_t* out, int 
  * Training: y (raw conv output, channel slice [0,C) of a [M,ld_y] buffer) -> z = relu((y-mean)*rstd+beta)
  * with batch statistics from `stats` (sum,sumsq as written by fn_conv2d_fwd); scale=rstd and
  * shift=beta-mean*rstd are saved for backward and the moving statistics are updated (biased variance). */
-int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, int M, int C, const float* stats, int stats_sq_off, const float* beta,
+int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, int M, int C, const float* stats, int stats_sq_off, int stats_replicas,
+                         int stats_rep_stride, const float* beta,
                          float* save_scale, float* save_shift, float* moving_mean, float* moving_var, float momentum, float eps,
                          int relu, int dtype, void* stream);
 /* backward: dz (grad wrt the BN+ReLU output) -> dy (grad wrt the raw conv output y), in place; y is the raw forward

@@ -43,10 +43,12 @@ def test_conv_fwd(lib, case, dt):
     w = _mk((Cout, kh, kw, Cin), dt, 0.1, seed=2)
     d = conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt)
     y = torch.full((N, d.OH, d.OW, Cout), 7.0, dtype=lp_dtype(dt), device="cuda")
-    stats = torch.zeros(2 * Cout, dtype=torch.float32, device="cuda")
-    d.x, d.w, d.y, d.stats, d.stats_sq_off = ptr(x), ptr(w), ptr(y), ptr(stats), Cout
+    reps = 4
+    stats_r = torch.zeros(reps, 2 * Cout, dtype=torch.float32, device="cuda")
+    d.x, d.w, d.y, d.stats, d.stats_sq_off, d.stats_replicas, d.stats_rep_stride = ptr(x), ptr(w), ptr(y), ptr(stats_r), Cout, reps, 2 * Cout
     _lib.check(lib.fn_conv2d_fwd(C.byref(d), stream()))
     torch.cuda.synchronize()
+    stats = stats_r.sum(0)            # row tiles are spread over the accumulator replicas
     ref = ref_conv(x, w, s, ph, pw)
     assert rel_err(y, ref) < (6e-3 if dt == _lib.FN_BF16 else 8e-4)
     # BatchNorm statistics come from the fp32 accumulators

@@ -52,7 +52,7 @@ def test_bn_relu_train_fwd_bwd(lib, dt, shape):
     z = torch.zeros(M, ld, dtype=lp_dtype(dt), device="cuda")
     sc, sh = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
     mm, mv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
-    _lib.check(lib.fn_bn_relu_train_fwd(ptr(ybuf, c0), ld, ptr(z, c0), ld, M, Cc, ptr(stats), Cc, ptr(beta), ptr(sc), ptr(sh), ptr(mm), ptr(mv),
+    _lib.check(lib.fn_bn_relu_train_fwd(ptr(ybuf, c0), ld, ptr(z, c0), ld, M, Cc, ptr(stats), Cc, 1, 0, ptr(beta), ptr(sc), ptr(sh), ptr(mm), ptr(mv),
                                         0.99, 1e-3, 1, dt, stream()))
     yr = yf.cpu().clone().requires_grad_(True)
     mean, var = yr.mean(0), yr.var(0, unbiased=False)
