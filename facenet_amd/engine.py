@@ -133,7 +133,8 @@ class Network:
 
     def __init__(self, embedding_size: int = 512, config: Optional[dict] = None, image_size: int = 160,
                  normalization: int = 0, nrof_classes: Optional[int] = None, device: str = "cuda",
-                 train_dtype: torch.dtype = torch.bfloat16, infer_dtype: torch.dtype = torch.float16, seed: int = 0):
+                 train_dtype: torch.dtype = torch.bfloat16, infer_dtype: torch.dtype = torch.float16, seed: int = 0,
+                 allocate: bool = True):
         self.cfg = {k: (dict(v) if isinstance(v, dict) else v) for k, v in DEFAULT_CONFIG.items()}
         if config:
             for k, v in config.items():
@@ -144,16 +145,19 @@ class Network:
         self.nrof_classes = nrof_classes
         self.device = torch.device(device)
         self.train_dtype, self.infer_dtype = train_dtype, infer_dtype
-        if self.device.type != "cuda":
+        # allocate=False: host-side description only (layer table, flat layout, variable counts) -- nothing is computed
+        if allocate and self.device.type != "cuda":
             raise _lib.FacenetHipError("facenet_amd runs on a HIP device only (no CPU fallback)")
-        self.lib = _lib.load()
+        self.lib = _lib.load() if allocate else None
 
         self.layers: "OrderedDict[str, Layer]" = OrderedDict()
         self.buf_bn: Dict[str, int] = {}     # buffer name -> BN channel offset
         self.CB = 0                          # size of the global BN channel space
+        self.G = None
         self._declare()
         self._layout()
-        self._alloc_params(seed)
+        if allocate:
+            self._alloc_params(seed)
 
     # ---- topology (written from inception_resnet_v1.py; independent of oracle/) ------------------
     def _topology(self, g: "Lowering"):

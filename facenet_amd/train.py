@@ -18,7 +18,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 
-from . import _lib
+from . import _lib, parallel
 from .engine import BN_EPS, L2_WEIGHT, Lowering, Network, _pad8, _ptr
 from .schedule import Op, Schedule, StreamSet, make_events, region, run_schedule, torch_op
 
@@ -157,28 +157,15 @@ class Trainer:
         done_at = {}
         for op_idx, li in self.plan.bwd_marks:
             done_at[li] = max(done_at.get(li, 0), op_idx)
-        for L in layers:   # classifier (softmax) finishes inside the loss ops, i.e. before backward starts
-            done_at.setdefault(L.index, 0)
-        total = net.n_kernel
-        target = total / n_buckets
-        buckets, hi, acc, ready = [], net.n_kernel, 0, 0
-        for L in reversed(layers):
-            acc += L.numel
-            ready = max(ready, done_at[L.index])
-            if acc >= target or L.index == 0:
-                buckets.append((ready, L.w_off, hi))
-                hi, acc = L.w_off, 0
-        # everything a bucket needs must be finished: make readiness monotone in issue order
-        out, r = [], 0
-        for (rd, lo, h) in buckets:
-            r = max(r, rd)
-            out.append((r, lo, h))
-        out.append((len(self.plan.bwd), net.n_decay, net.n_params))   # betas + biases, after the whole backward
-        return out
+        # the classifier (softmax) finishes inside the loss ops, i.e. before backward starts: done_at defaults to 0
+        tail = (net.n_decay, net.n_params)
+        buckets = parallel.make_buckets([L.w_off for L in layers], [L.numel for L in layers], done_at, net.n_kernel, tail,
+                                        len(self.plan.bwd), n_buckets)
+        parallel.check_buckets(buckets, net.n_kernel, tail)
+        return buckets
 
     def _allreduce(self, lo: int, hi: int):
-        import torch.distributed as dist
-        dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+        parallel.allreduce_bucket(self.G, lo, hi, self.pg)
 
     def _build_segments(self):
         """world 1: one schedule for the whole step.  world > 1: the backward is cut where a gradient bucket becomes

@@ -1,0 +1,95 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every symbol include/facenet_hip.h declares,
+the reference-API mirrors (Config, LearningRateScheduler, ImageProcessing), the flat parameter layout, and the
+bucket construction for data parallelism."""
+import os
+import re
+
+import pytest
+
+from facenet_amd import _lib, parallel
+from facenet_amd.config import Config, LoadConfigError, load_config
+from facenet_amd.engine import Network
+from facenet_amd.facenet import ImageProcessing, LearningRateScheduler, inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "facenet_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(fn_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 28
+    lib = _lib.load()
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in include/facenet_hip.h but not exported"
+    assert set(_lib.EXPORTS) == declared
+    assert lib.fn_abi_version() == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.FacenetHipError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_network_refuses_cpu_device():
+    with pytest.raises(_lib.FacenetHipError):
+        Network(embedding_size=128, device="cpu")
+
+
+def test_config_mirror():
+    c = Config({"a": {"b": 1}, "x": 2})
+    assert c.a.b == 1 and c.x == 2
+    assert not c.missing and not c.missing.deeper           # config.py:85-89: missing attribute -> empty falsy Config
+    assert c.as_dict == {"a": {"b": 1}, "x": 2} and c.exists("x") and not c.exists("y")
+    cfg = load_config()
+    assert cfg.batch_size == 100 and cfg.image.size == 160 and cfg.image.normalization == 0   # apps/configs/config.yaml:7,11,15
+    assert cfg.train.epoch.size == 1000 and cfg.train.epoch.nrof_epochs == 300                # train_softmax.yaml:37 ; config.py:181-182
+    with pytest.raises(LoadConfigError):
+        load_config("/nonexistent/file.yaml")
+
+
+def test_learning_rate_scheduler_and_image_processing():
+    sched = LearningRateScheduler(Config({"value": None, "schedule": [[100, 0.05], [200, 0.005], [300, 0.0005]]}))
+    assert [sched(e) for e in (0, 99, 100, 250, 300, 999)] == [0.05, 0.05, 0.005, 0.0005, 0.0005, 0.0005]
+    assert LearningRateScheduler(Config({"value": 0.01, "schedule": [[1, 9.0]]}))(0) == 0.01
+    img = Config({"size": 160, "normalization": 0})
+    assert inputs(img) == (160, 160, 3)
+    assert ImageProcessing(img).eps == 1e-3
+    with pytest.raises(ValueError):
+        ImageProcessing(Config({"size": 160, "normalization": 7}))             # facenet.py:82
+
+
+def test_flat_layout_and_counts_without_gpu():
+    net = Network(embedding_size=128, device="cpu", allocate=False)
+    assert net.count_variables() == (22808144, 22779312)
+    assert len(net.layers) == 133 and net.CB == sum(L.cout for L in net.layers.values() if L.has_bn)
+    offs = [(L.w_off, L.numel) for L in net.layers.values()]
+    assert offs[0][0] == 0 and all(a + n == b for (a, n), (b, _) in zip(offs, offs[1:]))      # kernels are contiguous
+    assert all(L.w_off % 8 == 0 and L.cin % 8 == 0 for L in net.layers.values())              # 16-B aligned packs
+    assert net.n_decay >= net.n_kernel and net.beta_base == net.n_decay and net.n_params % 4 == 0
+    first = net.layers["conv2d/Conv2d_1a_3x3"]
+    assert (first.cin, first.cin_real) == (8, 3)
+    # concat groups share one BN channel range in concat order (one BN pass per concat buffer)
+    b = net.buf_bn["block35/0/mixed"]
+    names = ["block35/0/tower_conv0/Conv2d_1x1", "block35/0/tower_conv1/Conv2d_0b_3x3", "block35/0/tower_conv2/Conv2d_0c_3x3"]
+    assert [net.layers[n].bn_off - b for n in names] == [0, 32, 64]
+    cls = Network(embedding_size=512, device="cpu", allocate=False, nrof_classes=10575)
+    L = cls.layers["classifier/logits"]
+    assert (L.cout, L.cout_real) == (10576, 10575)
+    assert cls.count_variables()[0] == 23497424 + 512 * 10575 + 10575
+
+
+def test_bucket_construction_covers_gradients_once():
+    net = Network(embedding_size=128, device="cpu", allocate=False)
+    layers = list(net.layers.values())
+    # backward finishes layers roughly last-to-first: emulate with op index = reverse declaration order
+    done_at = {L.index: 3 * (len(layers) - L.index) for L in layers}
+    tail = (net.n_decay, net.n_params)
+    for nb in (1, 4, 6, 16):
+        b = parallel.make_buckets([L.w_off for L in layers], [L.numel for L in layers], done_at, net.n_kernel, tail, 3 * len(layers) + 5, nb)
+        parallel.check_buckets(b, net.n_kernel, tail)
+        assert len(b) <= nb + 2 and b[-1][1:] == tail
+        assert b[0][2] == net.n_kernel and b[-2][1] == 0
+    with pytest.raises(AssertionError):
+        parallel.check_buckets([(0, 0, 10), (1, 20, 30)], 30, (30, 30))       # gap

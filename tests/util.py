@@ -44,18 +44,4 @@ def rel_err(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def structured_images(n, seed):
-    """Synthetic uint8 images with low-frequency structure, texture and per-image brightness / contrast, so that
-    different images produce different activations (pure white noise makes every image look alike to a CNN)."""
-    g = torch.Generator().manual_seed(seed)
-    out = []
-    for _ in range(n):
-        low = torch.rand(1, 3, 6, 6, generator=g)
-        img = torch.nn.functional.interpolate(low, size=(160, 160), mode="bicubic", align_corners=False)
-        fine = torch.rand(1, 3, 40, 40, generator=g)
-        img = img + 0.25 * torch.nn.functional.interpolate(fine, size=(160, 160), mode="bilinear", align_corners=False)
-        lo, hi = torch.rand(2, generator=g)
-        img = (img - img.min()) / (img.max() - img.min())
-        img = (0.5 * lo + (0.5 + 0.5 * hi - 0.5 * lo) * img) * 255
-        out.append(img[0].permute(1, 2, 0).clamp(0, 255).to(torch.uint8))
-    return torch.stack(out).numpy()
+from tests.util_data import structured_images  # noqa: E402,F401
