@@ -22,6 +22,8 @@
 //     and channel-slice output (ld_out) which makes tf.concat free.
 #include "common.h"
 #include "../../include/facenet_hip.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace fn {
 
@@ -42,6 +44,7 @@ struct ConvArgs {
     float scale;
     int tiles_m, tiles_n;
     int stats_sq_off, stats_replicas, stats_rep_stride;
+    int plain;  // 1x1 / stride 1 / no padding: source pixel == output pixel, k == channel
 };
 
 // Bijective XCD-aware remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
@@ -60,7 +63,7 @@ __device__ __forceinline__ int ktab_entry(int kgroup, int KTOT, int CS, int KW) 
     return (ky << 24) | (kx << 16) | c;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH>
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int BK = 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -87,7 +90,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int ntiles_k = (a.KTOT + BK - 1) / BK;
 
-    for (int i = tid; i < ntiles_k * 8; i += 256) sK[i] = ktab_entry(i, a.KTOT, a.CS, a.KW);
+    if constexpr (!PLAIN)
+        for (int i = tid; i < ntiles_k * 8; i += 256) sK[i] = ktab_entry(i, a.KTOT, a.CS, a.KW);
     if (tid < 2 * BN) sRed[tid] = 0.f;
 
     // per-thread gather rows
@@ -96,7 +100,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int m = m0 + r0 + 32 * i;
-        if (m < a.M) {
+        if constexpr (PLAIN) {
+            rowy[i] = (m < a.M) ? 0 : -1;
+            rowx[i] = 0;
+            rowbase[i] = m;
+        } else if (m < a.M) {
             const int n = m / (a.PH * a.PW), rem = m - n * a.PH * a.PW;
             const int py = rem / a.PW, px = rem - py * a.PW;
             rowy[i] = py * a.so + a.offy;
@@ -111,11 +119,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int dmask = (1 << a.dshift) - 1;
     __syncthreads();
 
-    // Two register sets: while tile kt is multiplied out of LDS, tile kt+1 sits in registers (loaded one phase ago)
-    // and the loads of tile kt+2 are in flight -- two global-load latencies are covered per K step, which is what
-    // these launches need: most layers of this network run at <= 1 workgroup per CU, so nothing else hides latency.
-    u32x4 ra0[AP], rb0[BP], ra1[AP], rb1[BP];
+    // DEPTH register stages: while tile kt is multiplied out of LDS, tiles kt+1 .. kt+DEPTH are loaded or in flight.
+    // Most layers of this network run at <= 1-2 workgroups per CU with cold per-XCD L2s at every kernel start, so
+    // nothing else hides the (MALL/HBM) load latency; small tiles have the registers to spare, large grids use DEPTH 1.
+    u32x4 ra[DEPTH][AP], rb[DEPTH][BP];   // tile t lives in register stage t % DEPTH
     auto load_tile = [&](int kt, u32x4 (&ra)[AP], u32x4 (&rb)[BP]) {
+        if constexpr (PLAIN) {
+            const int kk = kt * BK + kg * 8;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (rowy[i] == 0 && kk < a.KTOT) v = *reinterpret_cast<const u32x4*>(a.src + (long)rowbase[i] * a.ld_src + kk);
+                ra[i] = v;
+            }
+        } else {
         const int e = sK[kt * 8 + kg];
         const int ky = (e >> 24) & 0xff, kx = (e >> 16) & 0xff, c = e & 0xffff;
         const int dy = ky * a.sk, dx = kx * a.sk;
@@ -130,6 +147,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 v = *reinterpret_cast<const u32x4*>(a.src + off);
             }
             ra[i] = v;
+        }
         }
         const int k = kt * BK + kg * 8;
 #pragma unroll
@@ -182,32 +200,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         }
     };
 
-    if constexpr (DEPTH == 2) {
-        load_tile(0, ra0, rb0);
-        if (ntiles_k > 1) load_tile(1, ra1, rb1);
-        store_tile(0, ra0, rb0);
-        __syncthreads();
-        for (int kt = 0; kt < ntiles_k; kt += 2) {
-            if (kt + 2 < ntiles_k) load_tile(kt + 2, ra0, rb0);   // in flight across this phase AND the next
-            compute(0);
-            if (kt + 1 < ntiles_k) store_tile(1, ra1, rb1);       // loaded one phase ago
-            __syncthreads();
-            if (kt + 1 >= ntiles_k) break;
-            if (kt + 3 < ntiles_k) load_tile(kt + 3, ra1, rb1);
-            compute(1);
-            if (kt + 2 < ntiles_k) store_tile(0, ra0, rb0);
-            __syncthreads();
-        }
-    } else {   // one stage in registers: fewer VGPRs -> 3 workgroups per CU for the large grids
-        load_tile(0, ra0, rb0);
-        store_tile(0, ra0, rb0);
-        __syncthreads();
-        for (int kt = 0; kt < ntiles_k; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < ntiles_k) load_tile(kt + 1, ra0, rb0);
-            compute(buf);
-            if (kt + 1 < ntiles_k) store_tile(buf ^ 1, ra0, rb0);
-            __syncthreads();
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < ntiles_k) load_tile(d, ra[d], rb[d]);
+    store_tile(0, ra[0], rb[0]);
+    __syncthreads();
+    for (int kt0 = 0; kt0 < ntiles_k; kt0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int kt = kt0 + d;
+            if (kt < ntiles_k) {
+                // stage d held tile kt, already copied to LDS: refill it with tile kt+DEPTH (DEPTH loads stay in flight)
+                if (kt + DEPTH < ntiles_k) load_tile(kt + DEPTH, ra[d], rb[d]);
+                compute(kt & 1);
+                if (kt + 1 < ntiles_k) store_tile((kt + 1) & 1, ra[(d + 1) % DEPTH], rb[(d + 1) % DEPTH]);
+                __syncthreads();
+            }
         }
     }
 
@@ -317,8 +325,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH>
-static int launch_conv(const ConvArgs& a0, hipStream_t st) {
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN>
+static int launch_conv_p(const ConvArgs& a0, hipStream_t st) {
     ConvArgs a = a0;
     a.tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.NOUT, BN);
@@ -330,7 +338,7 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
         set_error("conv: K=%d needs %zu B of LDS (>160 KiB)", a.KTOT, smem);
         return FN_EUNSUPPORTED;
     }
-    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, DEPTH>;
+    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, DEPTH, PLAIN>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -338,6 +346,11 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), smem, st, a);
     return check_launch("conv_igemm");
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH>
+static int launch_conv(const ConvArgs& a, hipStream_t st) {
+    return a.plain ? launch_conv_p<T, BM, BN, WM, WN, DEPTH, true>(a, st) : launch_conv_p<T, BM, BN, WM, WN, DEPTH, false>(a, st);
 }
 
 // Tile choice.  BN: smallest padded width, ties -> larger tile.  BM: the largest of {128, 64, 32} that still gives
@@ -351,7 +364,7 @@ static void choose_conv_tile(int M, int NOUT, int& bm, int& bn) {
     }
     bm = 32;
     for (int c : {128, 64}) {
-        if ((long)cdiv(M, c) * cdiv(NOUT, bn) >= 512) { bm = c; break; }
+        if ((long)cdiv(M, c) * cdiv(NOUT, bn) >= 384) { bm = c; break; }
     }
     // narrow the N tile as well when even 32-row tiles leave most CUs idle
     while (bm == 32 && bn > 32 && (long)cdiv(M, 32) * cdiv(NOUT, bn) < 384) bn >>= 1;
@@ -360,19 +373,32 @@ static void choose_conv_tile(int M, int NOUT, int& bm, int& bn) {
 template <typename T> static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     int bm, bn;
     choose_conv_tile(a.M, a.NOUT, bm, bn);
+    if (const char* f = getenv("FN_CONV_TILE")) {   // tuning aid: "BMxBNxDEPTH"
+        int fm = 0, fnn = 0, fd = 0;
+        if (sscanf(f, "%dx%dx%d", &fm, &fnn, &fd) == 3) {
+            if (fm == 64 && fnn == 128 && fd == 4) return launch_conv<T, 64, 128, 1, 4, 4>(a, st);
+            if (fm == 64 && fnn == 64 && fd == 4) return launch_conv<T, 64, 64, 2, 2, 4>(a, st);
+            if (fm == 64 && fnn == 32 && fd == 4) return launch_conv<T, 64, 32, 2, 2, 4>(a, st);
+            if (fm == 64 && fnn == 128 && fd == 1) return launch_conv<T, 64, 128, 1, 4, 1>(a, st);
+            if (fm == 64 && fnn == 64 && fd == 1) return launch_conv<T, 64, 64, 2, 2, 1>(a, st);
+            if (fm == 128 && fnn == 128 && fd == 2) return launch_conv<T, 128, 128, 2, 2, 2>(a, st);
+            if (fm == 128 && fnn == 64 && fd == 2) return launch_conv<T, 128, 64, 2, 2, 2>(a, st);
+            bm = fm; bn = fnn;
+        }
+    }
     if (bm == 128) {
         if (bn == 128) return launch_conv<T, 128, 128, 2, 2, 1>(a, st);
         if (bn == 64) return launch_conv<T, 128, 64, 2, 2, 1>(a, st);
         return launch_conv<T, 128, 32, 4, 1, 1>(a, st);
     }
     if (bm == 64) {
-        if (bn == 128) return launch_conv<T, 64, 128, 1, 4, 1>(a, st);
-        if (bn == 64) return launch_conv<T, 64, 64, 2, 2, 1>(a, st);
-        return launch_conv<T, 64, 32, 2, 2, 1>(a, st);
+        if (bn == 128) return launch_conv<T, 64, 128, 1, 4, 2>(a, st);
+        if (bn == 64) return launch_conv<T, 64, 64, 2, 2, 2>(a, st);
+        return launch_conv<T, 64, 32, 2, 2, 2>(a, st);
     }
-    if (bn == 128) return launch_conv<T, 32, 128, 1, 4, 2>(a, st);
-    if (bn == 64) return launch_conv<T, 32, 64, 1, 4, 2>(a, st);
-    return launch_conv<T, 32, 32, 2, 2, 2>(a, st);
+    if (bn == 128) return launch_conv<T, 32, 128, 1, 4, 4>(a, st);
+    if (bn == 64) return launch_conv<T, 32, 64, 1, 4, 4>(a, st);
+    return launch_conv<T, 32, 32, 2, 2, 4>(a, st);
 }
 
 static int check_desc(const fn_conv_desc* d) {
@@ -412,6 +438,7 @@ struct WgradArgs {
 template <typename T, int BMW, int BNW>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr int BK = 64;                   // pixels per stage
+    constexpr int DEPTH = (BMW * BNW <= 64 * 64) ? 3 : (BMW * BNW <= 64 * 128 ? 2 : 1);   // register stages in flight
     constexpr int RSA = BMW * 2 + 32;        // LDS row strides in bytes (160 for 64, 288 for 128, 96 for 32)
     constexpr int RSB = BNW * 2 + 32;
     constexpr int A_BYTES = BK * RSA, B_BYTES = BK * RSB;
@@ -457,7 +484,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         acol[i] = c0 + (cidx % CGA) * 8;
     }
 
-    u32x4 ra0[AP], rb0[BP];
+    u32x4 ra[DEPTH][AP], rb[DEPTH][BP];
     auto load_tile = [&](int stg, u32x4 (&ra)[AP], u32x4 (&rb)[BP]) {
         const int mb = mbeg + stg * BK;
 #pragma unroll
@@ -537,15 +564,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         }
     };
 
-    load_tile(0, ra0, rb0);
-    store_tile(0, ra0, rb0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < nst) load_tile(d, ra[d], rb[d]);
+    store_tile(0, ra[0], rb[0]);
     __syncthreads();
-    for (int stg = 0; stg < nst; ++stg) {
-        const int buf = stg & 1;
-        if (stg + 1 < nst) load_tile(stg + 1, ra0, rb0);
-        compute(buf);
-        if (stg + 1 < nst) store_tile(buf ^ 1, ra0, rb0);
-        __syncthreads();
+    for (int s0 = 0; s0 < nst; s0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int stg = s0 + d;
+            if (stg < nst) {
+                if (stg + DEPTH < nst) load_tile(stg + DEPTH, ra[d], rb[d]);
+                compute(stg & 1);
+                if (stg + 1 < nst) store_tile((stg + 1) & 1, ra[(d + 1) % DEPTH], rb[(d + 1) % DEPTH]);
+                __syncthreads();
+            }
+        }
     }
 
     // C layout: col = lane&15 (kcol), row = (lane>>4)*4 + r (cout)
@@ -575,17 +609,37 @@ static void choose_wgrad_tile(int Cout, int KTOT, int& bmw, int& bnw) {
     bnw = (KTOT <= 64 || (cdiv(KTOT, 128) * 128 - KTOT) > 32) ? 64 : 128;
 }
 
+// Split-K factor over pixels.  Every split adds one fp32 copy of dW through global atomics (~1.3 TB/s chip-wide,
+// MI355X_MICROARCH.md) while fewer splits mean a longer serial stage chain per workgroup (~0.5 us per 64-pixel stage at
+// the occupancy these launches get).  Minimise  stages(s)*0.5us + s*bytes(dW)/1.3TB/s  subject to filling the chip.
+static int choose_wgrad_splits(int M, int Cout, int KTOT, int bmw, int bnw) {
+    const long tiles = (long)cdiv(KTOT, bnw) * cdiv(Cout, bmw);
+    const int stages = cdiv(M, 64);
+    if (stages >= 1024) {   // long chains (stem): ~1024 workgroups in total, at least 4 stages each
+        int s = (int)((1024 + tiles - 1) / tiles);
+        if (s > stages / 4) s = stages / 4;
+        return s < 1 ? 1 : s;
+    }
+    const double atom_us = (double)Cout * KTOT * 4.0 / 1.3e6;   // one fp32 copy of dW
+    int best = 1;
+    double best_t = 1e30;
+    for (int s = 1; s <= stages && s <= 512; s = (s < 8 ? s + 1 : s + s / 4)) {
+        const double waves = (double)(tiles * s) / 512.0;        // ~2 workgroups per CU resident
+        const double t = cdiv(stages, s) * 0.5 * (waves > 1.0 ? waves : 1.0) + s * atom_us;
+        if (t < best_t) { best_t = t; best = s; }
+    }
+    return best;
+}
+
 template <typename T> static int dispatch_wgrad(WgradArgs& a, int want_splits, hipStream_t st) {
     int bmw, bnw;
     choose_wgrad_tile(a.Cout, a.KTOT, bmw, bnw);
-    const long tiles = (long)cdiv(a.KTOT, bnw) * cdiv(a.Cout, bmw);
-    int splits = want_splits;
-    if (splits <= 0) {
-        splits = (int)((1024 + tiles - 1) / tiles);  // ~4 blocks per CU in total
-        const int maxs = cdiv(a.M, 256);             // at least 256 pixels per split
-        if (splits > maxs) splits = maxs;
-        if (splits < 1) splits = 1;
+    // small problems: prefer 64-wide tiles so that enough workgroups exist without a deep split
+    if ((long)cdiv(a.KTOT, bnw) * cdiv(a.Cout, bmw) < 64) {
+        if (bmw == 128) bmw = 64;
+        if (bnw == 128 && a.KTOT > 64) bnw = 64;
     }
+    int splits = want_splits > 0 ? want_splits : choose_wgrad_splits(a.M, a.Cout, a.KTOT, bmw, bnw);
     a.chunk = cdiv(cdiv(a.M, splits), 64) * 64;
     splits = cdiv(a.M, a.chunk);
     if (bmw == 32) return bnw == 64 ? launch_wgrad<T, 32, 64>(a, splits, st) : launch_wgrad<T, 32, 128>(a, splits, st);
@@ -611,6 +665,7 @@ extern "C" int fn_conv2d_fwd(const fn_conv_desc* d, void* stream) {
     a.ld_src = d->ld_x; a.ld_out = d->ld_y; a.ld_res = d->ld_res;
     a.relu = d->relu; a.accumulate = d->accumulate; a.out_f32 = d->out_f32; a.scale = d->scale;
     a.stats_sq_off = d->stats_sq_off;
+    a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0) ? 1 : 0;
     a.stats_replicas = d->stats_replicas > 0 ? d->stats_replicas : 1;
     a.stats_rep_stride = d->stats_rep_stride;
     return d->dtype == FN_BF16 ? dispatch_conv<__bf16>(a, (hipStream_t)stream) : dispatch_conv<_Float16>(a, (hipStream_t)stream);
@@ -629,6 +684,7 @@ extern "C" int fn_conv2d_dgrad(const fn_conv_desc* d, void* stream) {
     a.so = 1; a.sk = -1; a.offy = d->pad_h; a.offx = d->pad_w; a.dshift = d->stride == 2 ? 1 : 0;
     a.ld_src = d->ld_y; a.ld_out = d->ld_x; a.ld_res = 0;
     a.relu = 0; a.accumulate = d->accumulate; a.out_f32 = d->out_f32; a.scale = 1.f;
+    a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0) ? 1 : 0;
     return d->dtype == FN_BF16 ? dispatch_conv<__bf16>(a, (hipStream_t)stream) : dispatch_conv<_Float16>(a, (hipStream_t)stream);
 }
 
@@ -655,6 +711,12 @@ extern "C" int fn_conv2d_variant(const fn_conv_desc* d, int op) {
     int a, b;
     if (op == 0) choose_conv_tile(d->N * d->OH * d->OW, d->Cout, a, b);
     else if (op == 1) choose_conv_tile(d->N * d->H * d->W, d->Cin, a, b);
-    else choose_wgrad_tile(d->Cout, d->KH * d->KW * d->Cin, a, b);
+    else {
+        choose_wgrad_tile(d->Cout, d->KH * d->KW * d->Cin, a, b);
+        if ((long)cdiv(d->KH * d->KW * d->Cin, b) * cdiv(d->Cout, a) < 64) {
+            if (a == 128) a = 64;
+            if (b == 128 && d->KH * d->KW * d->Cin > 64) b = 64;
+        }
+    }
     return a * 1000 + b;
 }

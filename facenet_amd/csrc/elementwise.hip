@@ -99,28 +99,31 @@ __global__ __launch_bounds__(256) void gather_images_kernel(const uint8_t* __res
 // BatchNormalization(center only) + ReLU, training mode.  y (raw conv output) is KEPT: the backward
 // needs xhat for every element, including the ones ReLU clamps.
 // ------------------------------------------------------------------------------------------------
+// Grid = (row chunks, 64-channel stripes): a workgroup finalises the statistics of ITS stripe only (sum over the
+// accumulator replicas the convolution epilogue spread its row tiles over), so the replica count can be high
+// (same-address float atomics serialise) without every workgroup re-reading every channel.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* __restrict__ y, int ld_y, unsigned short* __restrict__ z,
                                                           int ld_z, int M, int C, const float* __restrict__ stats, int sq_off, int reps, int rep_stride,
                                                           const float* __restrict__ beta, float* __restrict__ save_scale,
                                                           float* __restrict__ save_shift, float* __restrict__ mm, float* __restrict__ mv,
-                                                          float momentum, float eps, int relu) {
-    extern __shared__ __attribute__((aligned(16))) float sh[];  // scale[C], shift[C]
-    float* s_scale = sh;
-    float* s_shift = sh + C;
-    const float invM = 1.f / (float)M;
-    for (int c = threadIdx.x; c < C; c += 256) {
+                                                          float momentum, float eps, int relu, int rows_per_block) {
+    __shared__ float s_scale[64], s_shift[64];
+    const int c0 = blockIdx.y * 64;
+    if (threadIdx.x < 64 && c0 + threadIdx.x < C) {
+        const int c = c0 + threadIdx.x;
         float s1 = 0.f, s2v = 0.f;
         for (int rp = 0; rp < reps; ++rp) {
             s1 += stats[(long)rp * rep_stride + c];
             s2v += stats[(long)rp * rep_stride + sq_off + c];
         }
+        const float invM = 1.f / (float)M;
         const float mean = s1 * invM;
         const float var = fmaxf(s2v * invM - mean * mean, 0.f);
         const float rstd = rsqrtf(var + eps);
         const float shf = beta[c] - mean * rstd;
-        s_scale[c] = rstd;
-        s_shift[c] = shf;
+        s_scale[threadIdx.x] = rstd;
+        s_shift[threadIdx.x] = shf;
         if (blockIdx.x == 0) {
             save_scale[c] = rstd;
             save_shift[c] = shf;
@@ -131,18 +134,23 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* 
         }
     }
     __syncthreads();
-    const int CG = C >> 3;
-    const long total = (long)M * CG;
-    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-        const int row = (int)(t / CG), cg = (int)(t - (long)row * CG);
+    const int ncg = min(8, (C - c0) >> 3);
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    if (tx >= ncg) return;
+    float sc[8], sf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = s_scale[tx * 8 + e]; sf[e] = s_shift[tx * 8 + e]; }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const int c = c0 + tx * 8;
+    for (int r = r0 + ty; r < r1; r += 32) {
         float v[8];
-        unpack8<T>(*reinterpret_cast<const u32x4*>(y + (long)row * ld_y + cg * 8), v);
+        unpack8<T>(*reinterpret_cast<const u32x4*>(y + (long)r * ld_y + c), v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float zf = fmaf(v[e], s_scale[cg * 8 + e], s_shift[cg * 8 + e]);
+            const float zf = fmaf(v[e], sc[e], sf[e]);
             v[e] = relu ? fmaxf(zf, 0.f) : zf;
         }
-        *reinterpret_cast<u32x4*>(z + (long)row * ld_z + cg * 8) = pack8<T>(v);
+        *reinterpret_cast<u32x4*>(z + (long)r * ld_z + c) = pack8<T>(v);
     }
 }
 
@@ -285,14 +293,27 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned short* 
                 bool win[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) win[e] = true;
+                // only the EARLIER positions need loading for the tie rule once the window maximum is known:
+                // I win iff x == max(window) and no earlier element equals it.  max(window) = max over later ones too,
+                // so later elements are still compared, but with <= (no tie break) -- identical result, same loads;
+                // the saving is the early exit for windows where this element is clearly not the maximum.
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     if (k == my) continue;
                     float v[8];
                     unpack8<T>(*reinterpret_cast<const u32x4*>(x + ((long)(n * H + 2 * oy + k / 3) * W + 2 * ox + k % 3) * ld_x + cg * 8), v);
+                    bool any = false;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) win[e] = win[e] && (k < my ? (v[e] < mine[e]) : (v[e] <= mine[e]));
+                    for (int e = 0; e < 8; ++e) {
+                        win[e] = win[e] && (k < my ? (v[e] < mine[e]) : (v[e] <= mine[e]));
+                        any = any || win[e];
+                    }
+                    if (!any) break;   // nobody in this channel group can still be the first maximum
                 }
+                bool any = false;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) any = any || win[e];
+                if (!any) continue;
                 float d[8];
                 unpack8<T>(*reinterpret_cast<const u32x4*>(dy + ((long)(n * OH + oy) * OW + ox) * ld_dy + cg * 8), d);
 #pragma unroll
@@ -541,9 +562,10 @@ extern "C" int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, 
     DT_CHECK(dtype);
     FN_REQUIRE(y && z && stats && beta && save_scale && save_shift && M > 0 && C > 0 && C % 8 == 0 && ld_y % 8 == 0 && ld_z % 8 == 0 &&
                    ld_y >= C && ld_z >= C && C <= 8192, "bn_fwd: bad arguments");
-    const int grid = grid_for((long)M * (C / 8), 256, 2048);
-    const size_t sm = 2 * C * sizeof(float);
-    LAUNCH_T(dtype, bn_relu_fwd_kernel, dim3(grid), dim3(256), sm, (hipStream_t)stream, (const unsigned short*)y, ld_y, (unsigned short*)z, ld_z, M, C, stats, stats_sq_off, stats_replicas > 0 ? stats_replicas : 1, stats_rep_stride, beta, save_scale, save_shift, moving_mean, moving_var, momentum, eps, relu);
+    const int stripes = cdiv(C, 64);
+    int rpb = cdiv((long)M * stripes, 2048);
+    if (rpb < 32) rpb = 32;
+    LAUNCH_T(dtype, bn_relu_fwd_kernel, dim3(cdiv(M, rpb), stripes), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)y, ld_y, (unsigned short*)z, ld_z, M, C, stats, stats_sq_off, stats_replicas > 0 ? stats_replicas : 1, stats_rep_stride, beta, save_scale, save_shift, moving_mean, moving_var, momentum, eps, relu, rpb);
     return check_launch("bn_relu_fwd");
 }
 

@@ -101,46 +101,54 @@ __global__ __launch_bounds__(1024) void select_triplets_kernel(const float* __re
         for (int i = 0; i < n; ++i) s_off[i + 1] += s_off[i];
     __syncthreads();
     const int Q = s_off[n];
+    // phase 1: thread per anchor writes the (a, p) of its pairs
     if (tid < n) {
-        const int a = tid;
-        int q = s_off[a];
-        for (int p = a + 1; p < n; ++p) {
-            if (s_lab[p] != s_lab[a]) continue;
-            const float dap = dist[(long)p * n + a];
-            int c = 0, others = 0;
-            for (int j = 0; j < n; ++j) {
-                if (s_lab[j] == s_lab[a]) continue;
-                ++others;
-                const float daj = dist[(long)j * n + a];
-                c += ((daj - dap < alpha) && (!semi_hard || daj > dap)) ? 1 : 0;
+        int q = s_off[tid];
+        for (int p = tid + 1; p < n; ++p)
+            if (s_lab[p] == s_lab[tid]) { rec[5 * q + 0] = tid; rec[5 * q + 1] = p; ++q; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // phase 2: one wave per pair; candidates are counted / picked with 64-wide ballots in index order
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int q = wave; q < Q; q += 16) {
+        const int a = rec[5 * q + 0], p = rec[5 * q + 1];
+        const int la = s_lab[a];
+        const float dap = dist[(long)p * n + a];
+        int c = 0, others = 0;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            const bool oth = (j < n) && (s_lab[j] != la);
+            const float daj = oth ? dist[(long)j * n + a] : 0.f;
+            const bool cand = oth && (daj - dap < alpha) && (!semi_hard || daj > dap);
+            c += __popcll(__ballot(cand));
+            others += __popcll(__ballot(oth));
+        }
+        const bool use_cand = c > 0;
+        int want = use_cand ? (int)(hash_u32(seed, (unsigned)q, 0u) % (unsigned)c)
+                            : (others > 0 ? (int)(hash_u32(seed, (unsigned)q, 2u) % (unsigned)others) : -1);
+        int neg = -1;
+        for (int j0 = 0; j0 < n && want >= 0; j0 += 64) {
+            const int j = j0 + lane;
+            const bool oth = (j < n) && (s_lab[j] != la);
+            const float daj = oth ? dist[(long)j * n + a] : 0.f;
+            const bool hit = use_cand ? (oth && (daj - dap < alpha) && (!semi_hard || daj > dap)) : oth;
+            const unsigned long long m = __ballot(hit);
+            const int cnt = __popcll(m);
+            if (want < cnt) {
+                const int rank = __popcll(m & ((1ull << lane) - 1ull));
+                const unsigned long long sel = __ballot(hit && rank == want);
+                neg = j0 + (int)__ffsll((long long)sel) - 1;
+                want = -1;
+            } else {
+                want -= cnt;
             }
-            int neg = -1, cls = 1;
-            if (c > 0) {
-                int want = (int)(hash_u32(seed, (unsigned)q, 0u) % (unsigned)c);
-                for (int j = 0; j < n; ++j) {
-                    if (s_lab[j] == s_lab[a]) continue;
-                    const float daj = dist[(long)j * n + a];
-                    if ((daj - dap < alpha) && (!semi_hard || daj > dap)) {
-                        if (want == 0) { neg = j; break; }
-                        --want;
-                    }
-                }
-                cls = 0;
-                atomicAdd(&s_nvalid, 1);
-            } else if (others > 0) {
-                int want = (int)(hash_u32(seed, (unsigned)q, 2u) % (unsigned)others);
-                for (int j = 0; j < n; ++j) {
-                    if (s_lab[j] == s_lab[a]) continue;
-                    if (want == 0) { neg = j; break; }
-                    --want;
-                }
-            }
-            rec[5 * q + 0] = a;
-            rec[5 * q + 1] = p;
+        }
+        if (lane == 0) {
             rec[5 * q + 2] = neg;
             rec[5 * q + 3] = (int)hash_u32(seed, (unsigned)q, 1u);
-            rec[5 * q + 4] = cls;
-            ++q;
+            rec[5 * q + 4] = use_cand ? 0 : 1;
+            if (use_cand) atomicAdd(&s_nvalid, 1);
         }
     }
     __threadfence_block();

@@ -33,7 +33,7 @@ from .schedule import Op, Region, region
 BN_EPS = 1e-3        # Keras default (inception_resnet_v1.py:57-58 commented out)
 BN_MOMENTUM = 0.99   # Keras default
 L2_WEIGHT = 5e-4     # inception_resnet_v1.py:65
-STAT_REPLICAS = 16   # BN-statistic accumulator replicas (engine-internal)
+STAT_REPLICAS = 32   # max BN-statistic accumulator replicas (engine-internal)
 
 DEFAULT_CONFIG = {   # inception_resnet_v1.py:13-43
     "reduction_a": {"filters": [[384], [192, 192, 256]]},
@@ -532,7 +532,10 @@ class Lowering:
     def _replicas(M: int) -> int:
         """Accumulator replicas for the conv-epilogue BN statistics: thousands of row tiles adding into one address
         serialise at the memory side (MI355X_MICROARCH.md 'Global float atomics')."""
-        return STAT_REPLICAS if M >= 100000 else (4 if M >= 20000 else 1)
+        r = 1
+        while r < STAT_REPLICAS and M // (64 * r) > 8:    # ~<= 8 row tiles add into one replica
+            r *= 2
+        return r
 
     def _emit(self, lst: List[Op], name: str, fn, *args, keep=(), r=(), w=()):
         lst.append(Op(name, fn, args, tuple(keep), tuple(r), tuple(w)))

@@ -26,17 +26,13 @@ def bench(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt=_lib.FN_F16, stats=False, re
     fl = 2.0 * N * d.OH * d.OW * Cout * kh * kw * Cin
     v = lib.fn_conv2d_variant(C.byref(d), 0)
     print(f"N{N} {H}x{W}x{Cin}->{Cout} k{kh}x{kw}s{s} tile {v//1000}x{v%1000} K={kh*kw*Cin:5d} ktiles={(kh*kw*Cin+63)//64:3d} : {us:7.2f} us  {fl/us/1e6:7.1f} TF/s stats={stats}")
-print("--- block17-like M=5760 N=128, vary K")
-for cin in (64, 128, 256, 512, 896, 1792): bench(90, 8, 8, cin, 128, 1, 1, 1, 0, 0)
-print("--- M=11520 (N180)")
-for cin in (64, 896): bench(180, 8, 8, cin, 128, 1, 1, 1, 0, 0)
-print("--- block8-like M=810 N=192")
-for cin in (64, 192, 576, 1792): bench(90, 3, 3, cin, 192, 1, 1, 1, 0, 0)
-print("--- block35-like M=26010 N=32")
-for cin in (32, 64, 256): bench(90, 17, 17, cin, 32, 1, 1, 1, 0, 0)
-bench(90, 17, 17, 32, 32, 3, 3, 1, 1, 1)
-print("--- big: 4a, 4b")
-bench(90, 37, 37, 80, 192, 3, 3, 1, 0, 0); bench(90, 35, 35, 192, 256, 3, 3, 2, 0, 0); bench(90, 77, 77, 32, 64, 3, 3, 1, 0, 0)
-print("--- stats epilogue on/off (bf16)")
-bench(90, 8, 8, 896, 128, 1, 1, 1, 0, 0, _lib.FN_BF16, False); bench(90, 8, 8, 896, 128, 1, 1, 1, 0, 0, _lib.FN_BF16, True)
-bench(90, 79, 79, 32, 32, 3, 3, 1, 0, 0, _lib.FN_BF16, False); bench(90, 79, 79, 32, 32, 3, 3, 1, 0, 0, _lib.FN_BF16, True)
+import os
+shapes = [("b17 1x1", (90, 8, 8, 896, 128, 1, 1, 1, 0, 0)), ("b17 1x7", (90, 8, 8, 128, 128, 1, 7, 1, 0, 3)), ("b17 up", (90, 8, 8, 256, 896, 1, 1, 1, 0, 0)),
+          ("b35 1x1", (90, 17, 17, 256, 32, 1, 1, 1, 0, 0)), ("b35 3x3", (90, 17, 17, 32, 32, 3, 3, 1, 1, 1)), ("b35 up", (90, 17, 17, 96, 256, 1, 1, 1, 0, 0)),
+          ("b8 1x1", (90, 3, 3, 1792, 192, 1, 1, 1, 0, 0)), ("b8 1x3", (90, 3, 3, 192, 192, 1, 3, 1, 0, 1)), ("b8 up", (90, 3, 3, 384, 1792, 1, 1, 1, 0, 0)),
+          ("redA 3x3", (90, 17, 17, 192, 192, 3, 3, 1, 1, 1)), ("4a", (90, 37, 37, 80, 192, 3, 3, 1, 0, 0)), ("4b", (90, 35, 35, 192, 256, 3, 3, 2, 0, 0)), ("2b", (90, 77, 77, 32, 64, 3, 3, 1, 0, 0))]
+for tile in (None, "32x32x4", "32x64x4", "64x32x4", "64x64x4", "64x64x1", "64x128x4", "64x128x1", "128x64x2", "128x128x2", "128x64x1", "128x128x1"):
+    if tile: os.environ["FN_CONV_TILE"] = tile
+    print("=== tile", tile or "auto")
+    for name, sh in shapes:
+        print(f"{name:9s}", end=" "); bench(*sh, dt=_lib.FN_BF16, stats=True)
