@@ -159,13 +159,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; FACENET_DIST_BACKEND=gloo lets the whole data-parallel path be rehearsed with several ranks on
+    # ONE GPU (RCCL refuses two ranks on a device), which is how it is tested on the single-GPU development box
+    backend = os.environ.get("FACENET_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, ndev)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # backend "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # backend "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
         pg = dist.group.WORLD
 
     from facenet_amd import _lib

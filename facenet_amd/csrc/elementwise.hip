@@ -108,15 +108,27 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* 
                                                           const float* __restrict__ beta, float* __restrict__ save_scale,
                                                           float* __restrict__ save_shift, float* __restrict__ mm, float* __restrict__ mv,
                                                           float momentum, float eps, int relu, int rows_per_block) {
-    __shared__ float s_scale[64], s_shift[64];
+    __shared__ float s_scale[64], s_shift[64], s_part[4][2][64];
     const int c0 = blockIdx.y * 64;
+    {   // replica sums: 4 thread groups x 64 channels, independent loads in flight (a rolled serial loop would expose
+        // one memory latency per replica)
+        const int cc = threadIdx.x & 63, q = threadIdx.x >> 6;
+        float s1 = 0.f, s2v = 0.f;
+        if (c0 + cc < C) {
+#pragma unroll 4
+            for (int rp = q; rp < reps; rp += 4) {
+                s1 += stats[(long)rp * rep_stride + c0 + cc];
+                s2v += stats[(long)rp * rep_stride + sq_off + c0 + cc];
+            }
+        }
+        s_part[q][0][cc] = s1;
+        s_part[q][1][cc] = s2v;
+    }
+    __syncthreads();
     if (threadIdx.x < 64 && c0 + threadIdx.x < C) {
         const int c = c0 + threadIdx.x;
-        float s1 = 0.f, s2v = 0.f;
-        for (int rp = 0; rp < reps; ++rp) {
-            s1 += stats[(long)rp * rep_stride + c];
-            s2v += stats[(long)rp * rep_stride + sq_off + c];
-        }
+        const float s1 = s_part[0][0][threadIdx.x] + s_part[1][0][threadIdx.x] + s_part[2][0][threadIdx.x] + s_part[3][0][threadIdx.x];
+        const float s2v = s_part[0][1][threadIdx.x] + s_part[1][1][threadIdx.x] + s_part[2][1][threadIdx.x] + s_part[3][1][threadIdx.x];
         const float invM = 1.f / (float)M;
         const float mean = s1 * invM;
         const float var = fmaxf(s2v * invM - mean * mean, 0.f);
@@ -135,14 +147,16 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* 
     }
     __syncthreads();
     const int ncg = min(8, (C - c0) >> 3);
-    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const int TX = ncg <= 1 ? 1 : (ncg <= 2 ? 2 : (ncg <= 4 ? 4 : 8));   // narrow stripes keep all 256 threads busy
+    const int TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     if (tx >= ncg) return;
     float sc[8], sf[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = s_scale[tx * 8 + e]; sf[e] = s_shift[tx * 8 + e]; }
     const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
     const int c = c0 + tx * 8;
-    for (int r = r0 + ty; r < r1; r += 32) {
+    for (int r = r0 + ty; r < r1; r += TY) {
         float v[8];
         unpack8<T>(*reinterpret_cast<const u32x4*>(y + (long)r * ld_y + c), v);
 #pragma unroll
@@ -166,7 +180,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const unsigned 
     __shared__ float red[32][2 * 64 + 1];
     const int c0 = blockIdx.y * 64;
     const int ncg = min(8, (C - c0) >> 3);          // 16-B channel groups in this stripe
-    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;   // 8 channel groups x 32 row lanes
+    const int TX = ncg <= 1 ? 1 : (ncg <= 2 ? 2 : (ncg <= 4 ? 4 : 8));
+    const int TY = 256 / TX;                        // 32 .. 256 row lanes
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
     float a1[8], a2[8];
@@ -177,7 +193,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const unsigned 
         float b[8], sc[8], sf[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { b[e] = beta[c + e]; sc[e] = scale[c + e]; sf[e] = shift[c + e]; }
-        for (int r = r0 + ty; r < r1; r += 32) {
+        for (int r = r0 + ty; r < r1; r += TY) {
             float g[8], yy[8];
             unpack8<T>(*reinterpret_cast<const u32x4*>(dz + (long)r * ld_d + c), g);
             unpack8<T>(*reinterpret_cast<const u32x4*>(y + (long)r * ld_y + c), yy);
@@ -190,16 +206,26 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const unsigned 
             }
         }
     }
+    // fold the TY row lanes down to 32 with shuffles-free LDS passes: lanes ty and ty+32k share red[ty & 31]
+    for (int pass = 0; pass < TY / 32; ++pass) {
+        if (ty / 32 == pass && tx < ncg) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { red[ty][tx * 8 + e] = a1[e]; red[ty][64 + tx * 8 + e] = a2[e]; }
-    __syncthreads();
+            for (int e = 0; e < 8; ++e) {
+                if (pass == 0) { red[ty & 31][tx * 8 + e] = a1[e]; red[ty & 31][64 + tx * 8 + e] = a2[e]; }
+                else { red[ty & 31][tx * 8 + e] += a1[e]; red[ty & 31][64 + tx * 8 + e] += a2[e]; }
+            }
+        }
+        __syncthreads();
+    }
     if (threadIdx.x < 128) {
         const int col = threadIdx.x;   // 0..63 -> dbeta, 64..127 -> s2
-        float s = 0.f;
-#pragma unroll 8
-        for (int t = 0; t < 32; ++t) s += red[t][col];
         const int c = c0 + (col & 63);
-        if (c < C) atomicAdd(col < 64 ? &dbeta[c] : &s2[c], s);
+        if (c < C && (col & 63) < ncg * 8) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int t = 0; t < 32; ++t) s += red[t][col];
+            atomicAdd(col < 64 ? &dbeta[c] : &s2[c], s);
+        }
     }
 }
 

@@ -33,7 +33,7 @@ from .schedule import Op, Region, region
 BN_EPS = 1e-3        # Keras default (inception_resnet_v1.py:57-58 commented out)
 BN_MOMENTUM = 0.99   # Keras default
 L2_WEIGHT = 5e-4     # inception_resnet_v1.py:65
-STAT_REPLICAS = 32   # max BN-statistic accumulator replicas (engine-internal)
+STAT_REPLICAS = 16   # max BN-statistic accumulator replicas (engine-internal)
 
 DEFAULT_CONFIG = {   # inception_resnet_v1.py:13-43
     "reduction_a": {"filters": [[384], [192, 192, 256]]},
@@ -533,7 +533,7 @@ class Lowering:
         """Accumulator replicas for the conv-epilogue BN statistics: thousands of row tiles adding into one address
         serialise at the memory side (MI355X_MICROARCH.md 'Global float atomics')."""
         r = 1
-        while r < STAT_REPLICAS and M // (64 * r) > 8:    # ~<= 8 row tiles add into one replica
+        while r < STAT_REPLICAS and M // (64 * r) > 32:   # ~<= 32 row tiles add into one replica
             r *= 2
         return r
 
