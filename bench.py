@@ -59,20 +59,46 @@ def time_ops_individually(ops, stream, lib, reps=3):
     return times
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of one conv instantiation from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    profiles/r01_pmc_hbm_traffic.json); None when the profile is absent."""
+    import re
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    m = re.match(r"(conv_igemm_kernel|conv_wgrad_kernel|conv_wgrad_grouped_kernel)<(__bf16|_Float16),(\d+),(\d+)>", kernel_key)
+    if not (m and os.path.exists(path)):
+        return None
+    pat = f"{m.group(1)}I{'DF16b' if m.group(2) == '__bf16' else 'DF16_'}Li{m.group(3)}ELi{m.group(4)}E"
+    n = tot = 0.0
+    for name, v in json.load(open(path))["kernels"].items():
+        if pat in name:
+            n += v["launches"]
+            tot += v["launches"] * v["hbm_bytes_per_launch"]
+    return round(tot / n) if n else None
+
+
 def kernel_roofline(trainer, miner, lib, dump=None):
     """Attribute event-timed launches to kernel instantiations; report the dominant one against its roofline."""
     import ctypes as C
     net = trainer.net
     st = net.stream()
     groups = {}
-    all_ops = list(miner.ops) + list(trainer.plan.fwd) + list(trainer.loss_ops) + list(trainer.plan.bwd) + list(trainer.opt_ops)
+    all_ops = list(miner.ops) + [op for op in trainer.step_ops if not getattr(op.fn, "_torch_op", False)]
     trainer._zero()
     torch.cuda.synchronize()
     t = time_ops_individually(all_ops, st, lib)
     per_op = []
     for op, ms in zip(all_ops, t):
         kind = op.name.split(":")[0]
-        if kind in ("conv_fwd", "conv_dgrad", "conv_wgrad") and op.keep:
+        if kind == "conv_wgrad_grouped":
+            descs = op.keep[0]
+            tname = "__bf16" if descs[0].dtype == 0 else "_Float16"
+            key = f"conv_wgrad_grouped_kernel<{tname},{op.name.split(':')[1].replace('x', ',')}>"
+            fl = sum(conv_flops(d, 2) for d in descs)
+            g = groups.setdefault(key, dict(ms=0.0, flops=0.0, launches=0, bound="mfma"))
+            g["flops"] += fl
+            per_op.append(dict(op=op.name, kernel=key, us=round(ms * 1e3, 2), gflop=round(fl / 1e9, 3), layers=len(descs),
+                               tflops=round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0))
+        elif kind in ("conv_fwd", "conv_dgrad", "conv_wgrad") and op.keep:
             d = op.keep[0]
             opi = {"conv_fwd": 0, "conv_dgrad": 1, "conv_wgrad": 2}[kind]
             v = lib.fn_conv2d_variant(C.byref(d), opi)
@@ -100,7 +126,7 @@ def kernel_roofline(trainer, miner, lib, dump=None):
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
     roof = {
         "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(name),
         "launches_per_step": g["launches"], "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
         "share_of_step_kernel_time": round(g["ms"] / total_ms, 3),
         "flop_per_launch_avg": round(g["flops"] / g["launches"], 0),

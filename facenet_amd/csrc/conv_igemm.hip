@@ -428,6 +428,7 @@ struct WgradArgs {
     int stride, pad_h, pad_w;
     int ld_x, ld_y;
     int chunk;  // pixels per split (multiple of 64)
+    int gx, gy, splits;  // grid of this layer inside a grouped launch
     int plain;  // 1x1 stride-1: source pixel == output pixel
     float inv_ow, inv_ohw;
 };
@@ -436,7 +437,7 @@ struct WgradArgs {
 //   rho = q + 4*(g&1) + 8*h + 16*(g>>1)   -> the 8 rows a 32-lane half reads per ds_read_b64_tr_b16
 //   are distinct mod 8, which with row strides of 160 B / 288 B makes the transposed reads conflict free.
 template <typename T, int BMW, int BNW>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+__device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bx, const int by, const int bz) {
     constexpr int BK = 64;                   // pixels per stage
     constexpr int DEPTH = (BMW * BNW <= 64 * 64) ? 3 : (BMW * BNW <= 64 * 128 ? 2 : 1);   // register stages in flight
     constexpr int RSA = BMW * 2 + 32;        // LDS row strides in bytes (160 for 64, 288 for 128, 96 for 32)
@@ -456,9 +457,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WNW, wn = wave % WNW;
-    const int n0 = blockIdx.x * BNW;  // kcol tile
-    const int c0 = blockIdx.y * BMW;  // cout tile
-    const int mbeg = blockIdx.z * a.chunk;
+    const int n0 = bx * BNW;  // kcol tile
+    const int c0 = by * BMW;  // cout tile
+    const int mbeg = bz * a.chunk;
     const int mend = min(a.M, mbeg + a.chunk);
     const int nst = (mend - mbeg + BK - 1) / BK;
     if (nst <= 0) return;
@@ -596,6 +597,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         }
 }
 
+template <typename T, int BMW, int BNW>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+    conv_wgrad_body<T, BMW, BNW>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped form: ONE launch computes the weight gradients of many layers.  Weight gradients have no consumer before the
+// optimiser, so the engine defers them to the end of backward and issues them per tile configuration: thousands of
+// workgroups per launch instead of 133 launches that each fill a fraction of the 256 CUs.
+// args[g] describes layer g; prefix[g] .. prefix[g+1] are its workgroups (gx * gy * splits).
+template <typename T, int BMW, int BNW>
+__global__ __launch_bounds__(256) void conv_wgrad_grouped_kernel(const WgradArgs* __restrict__ args, const int* __restrict__ prefix, int n) {
+    const int bid = blockIdx.x;
+    int lo = 0, hi = n;                    // largest g with prefix[g] <= bid
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= bid) lo = mid; else hi = mid;
+    }
+    const WgradArgs a = args[lo];
+    const int local = bid - prefix[lo];
+    const int gxy = a.gx * a.gy;
+    const int bz = local / gxy, r = local - bz * gxy;
+    conv_wgrad_body<T, BMW, BNW>(a, r % a.gx, r / a.gx, bz);
+}
+
 template <typename T, int BMW, int BNW> static int launch_wgrad(const WgradArgs& a, int splits, hipStream_t st) {
     constexpr int RSA = BMW * 2 + 32, RSB = BNW * 2 + 32;
     const size_t smem = 2 * 64 * (RSA + RSB);
@@ -631,17 +656,34 @@ static int choose_wgrad_splits(int M, int Cout, int KTOT, int bmw, int bnw) {
     return best;
 }
 
-template <typename T> static int dispatch_wgrad(WgradArgs& a, int want_splits, hipStream_t st) {
-    int bmw, bnw;
-    choose_wgrad_tile(a.Cout, a.KTOT, bmw, bnw);
+static void final_wgrad_tile(int Cout, int KTOT, int& bmw, int& bnw) {
+    choose_wgrad_tile(Cout, KTOT, bmw, bnw);
     // small problems: prefer 64-wide tiles so that enough workgroups exist without a deep split
-    if ((long)cdiv(a.KTOT, bnw) * cdiv(a.Cout, bmw) < 64) {
+    if ((long)cdiv(KTOT, bnw) * cdiv(Cout, bmw) < 64) {
         if (bmw == 128) bmw = 64;
-        if (bnw == 128 && a.KTOT > 64) bnw = 64;
+        if (bnw == 128 && KTOT > 64) bnw = 64;
     }
+}
+
+static int plan_wgrad(WgradArgs& a, int want_splits, int bmw, int bnw, bool grouped) {
     int splits = want_splits > 0 ? want_splits : choose_wgrad_splits(a.M, a.Cout, a.KTOT, bmw, bnw);
+    if (grouped && want_splits <= 0) {
+        // inside a grouped launch the chip is full anyway: fewer, longer splits (less atomic traffic), >= 8 stages each
+        const int cap = cdiv(cdiv(a.M, 64), 8);
+        if (splits > cap) splits = cap < 1 ? 1 : cap;
+    }
     a.chunk = cdiv(cdiv(a.M, splits), 64) * 64;
     splits = cdiv(a.M, a.chunk);
+    a.gx = cdiv(a.KTOT, bnw);
+    a.gy = cdiv(a.Cout, bmw);
+    a.splits = splits;
+    return splits;
+}
+
+template <typename T> static int dispatch_wgrad(WgradArgs& a, int want_splits, hipStream_t st) {
+    int bmw, bnw;
+    final_wgrad_tile(a.Cout, a.KTOT, bmw, bnw);
+    const int splits = plan_wgrad(a, want_splits, bmw, bnw, false);
     if (bmw == 32) return bnw == 64 ? launch_wgrad<T, 32, 64>(a, splits, st) : launch_wgrad<T, 32, 128>(a, splits, st);
     if (bmw == 64) return bnw == 64 ? launch_wgrad<T, 64, 64>(a, splits, st) : launch_wgrad<T, 64, 128>(a, splits, st);
     return bnw == 64 ? launch_wgrad<T, 128, 64>(a, splits, st) : launch_wgrad<T, 128, 128>(a, splits, st);
@@ -688,20 +730,75 @@ extern "C" int fn_conv2d_dgrad(const fn_conv_desc* d, void* stream) {
     return d->dtype == FN_BF16 ? dispatch_conv<__bf16>(a, (hipStream_t)stream) : dispatch_conv<_Float16>(a, (hipStream_t)stream);
 }
 
-extern "C" int fn_conv2d_wgrad(const fn_conv_desc* d, void* stream) {
+static int make_wgrad_args(const fn_conv_desc* d, WgradArgs& a) {
     if (int rc = check_desc(d)) return rc;
     FN_REQUIRE(d->x && d->y && d->dw, "conv_wgrad: null x/dy/dw");
     FN_REQUIRE(d->ld_y % 8 == 0 && d->ld_y >= d->Cout, "conv_wgrad: ld_y=%d invalid", d->ld_y);
     FN_REQUIRE((long)d->N * d->OH * d->OW < (1L << 24), "conv_wgrad: N*OH*OW must be < 2^24");
-    WgradArgs a{};
+    a = WgradArgs{};
     a.x = (const unsigned short*)d->x; a.dy = (const unsigned short*)d->y; a.dw = d->dw;
     a.M = d->N * d->OH * d->OW; a.OH = d->OH; a.OW = d->OW; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
     a.KTOT = d->KH * d->KW * d->Cin; a.KW = d->KW; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
     a.ld_x = d->ld_x; a.ld_y = d->ld_y;
     a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0) ? 1 : 0;
     a.inv_ow = 1.0f / (float)d->OW; a.inv_ohw = 1.0f / (float)(d->OH * d->OW);
+    return FN_OK;
+}
+
+extern "C" int fn_conv2d_wgrad(const fn_conv_desc* d, void* stream) {
+    WgradArgs a;
+    if (int rc = make_wgrad_args(d, a)) return rc;
     return d->dtype == FN_BF16 ? dispatch_wgrad<__bf16>(a, d->splits, (hipStream_t)stream)
                                : dispatch_wgrad<_Float16>(a, d->splits, (hipStream_t)stream);
+}
+
+// ---- grouped weight gradients ------------------------------------------------------------------------------------
+extern "C" int fn_conv2d_wgrad_arg_bytes(void) { return (int)sizeof(WgradArgs); }
+
+// Host-side planning: fills host_args[n * fn_conv2d_wgrad_arg_bytes()] and host_prefix[n+1] for n descriptors that all
+// dispatch to `variant` (= fn_conv2d_variant(desc, 2)); returns the total number of workgroups (or a negative status).
+extern "C" int fn_conv2d_wgrad_group_build(const fn_conv_desc* descs, int n, int variant, void* host_args, int32_t* host_prefix) {
+    FN_REQUIRE(descs && host_args && host_prefix && n > 0, "wgrad_group_build: bad arguments");
+    const int bmw = variant / 1000, bnw = variant % 1000;
+    WgradArgs* out = reinterpret_cast<WgradArgs*>(host_args);
+    long total = 0;
+    for (int i = 0; i < n; ++i) {
+        WgradArgs a;
+        if (int rc = make_wgrad_args(&descs[i], a)) return rc;
+        int m, k;
+        final_wgrad_tile(a.Cout, a.KTOT, m, k);
+        FN_REQUIRE(m == bmw && k == bnw, "wgrad_group_build: descriptor %d dispatches to %dx%d, group is %dx%d", i, m, k, bmw, bnw);
+        FN_REQUIRE(descs[i].dtype == descs[0].dtype, "wgrad_group_build: mixed dtypes");
+        const int splits = plan_wgrad(a, descs[i].splits, bmw, bnw, true);
+        host_prefix[i] = (int32_t)total;
+        total += (long)a.gx * a.gy * splits;
+        out[i] = a;
+    }
+    FN_REQUIRE(total < (1L << 30), "wgrad_group_build: too many workgroups");
+    host_prefix[n] = (int32_t)total;
+    return (int)total;
+}
+
+template <typename T> static int launch_wgrad_grouped(const void* args, const int32_t* prefix, int n, int total, int variant, hipStream_t st) {
+    const int bmw = variant / 1000, bnw = variant % 1000;
+    const WgradArgs* a = reinterpret_cast<const WgradArgs*>(args);
+#define FN_WG(BM_, BN_)                                                                                                     \
+    if (bmw == BM_ && bnw == BN_) {                                                                                         \
+        hipLaunchKernelGGL((conv_wgrad_grouped_kernel<T, BM_, BN_>), dim3(total), dim3(256), 2 * 64 * ((BM_) * 2 + 32 + (BN_) * 2 + 32), st, a, prefix, n); \
+        return check_launch("conv_wgrad_grouped");                                                                          \
+    }
+    FN_WG(32, 64) FN_WG(32, 128) FN_WG(64, 64) FN_WG(64, 128) FN_WG(128, 64) FN_WG(128, 128)
+#undef FN_WG
+    set_error("wgrad_grouped: unknown variant %d", variant);
+    return FN_EINVAL;
+}
+
+extern "C" int fn_conv2d_wgrad_grouped(const void* dev_args, const int32_t* dev_prefix, int n, int total_blocks, int variant, int dtype,
+                                       void* stream) {
+    FN_REQUIRE(dev_args && dev_prefix && n > 0 && total_blocks > 0, "wgrad_grouped: bad arguments");
+    FN_REQUIRE(dtype == FN_BF16 || dtype == FN_F16, "dtype %d unsupported", dtype);
+    return dtype == FN_BF16 ? launch_wgrad_grouped<__bf16>(dev_args, dev_prefix, n, total_blocks, variant, (hipStream_t)stream)
+                            : launch_wgrad_grouped<_Float16>(dev_args, dev_prefix, n, total_blocks, variant, (hipStream_t)stream);
 }
 
 // Which kernel instantiation a descriptor dispatches to: returns BM*1000 + BN (op 0 = fwd, 1 = dgrad) or
@@ -711,12 +808,6 @@ extern "C" int fn_conv2d_variant(const fn_conv_desc* d, int op) {
     int a, b;
     if (op == 0) choose_conv_tile(d->N * d->OH * d->OW, d->Cout, a, b);
     else if (op == 1) choose_conv_tile(d->N * d->H * d->W, d->Cin, a, b);
-    else {
-        choose_wgrad_tile(d->Cout, d->KH * d->KW * d->Cin, a, b);
-        if ((long)cdiv(d->KH * d->KW * d->Cin, b) * cdiv(d->Cout, a) < 64) {
-            if (a == 128) a = 64;
-            if (b == 128 && d->KH * d->KW * d->Cin > 64) b = 64;
-        }
-    }
+    else final_wgrad_tile(d->Cout, d->KH * d->KW * d->Cin, a, b);
     return a * 1000 + b;
 }

@@ -48,20 +48,34 @@ __global__ void adam_tick_kernel(float* hyper, float beta1, float beta2) {
     hyper[2] *= beta2;
 }
 
-// one workgroup column (blockIdx.y = layer); table row = {w_off, cout, ktot, taps, cin, bn_off, fold_bias_off, 0}
+// one workgroup column per layer (blockIdx.y); table row = {w_off, cout, ktot, taps, cin, bn_off, fold_bias_off, 0}.
+// Tiled through LDS: for every tap a [cout][cin] -> [cin][cout] transpose in 32x32 tiles, both sides coalesced
+// (the naive destination-linear gather fetched ~10x the bytes: profiles/r01_pmc_hbm_traffic.json).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_transpose_kernel(const unsigned short* __restrict__ w, unsigned short* __restrict__ wt,
                                                              const int* __restrict__ table) {
+    __shared__ unsigned short tile[32][33];
     const int* row = table + 8 * blockIdx.y;
     const long off = row[0];
-    const int cout = row[1], ktot = row[2], taps = row[3], cin = row[4];
-    const long total = (long)cout * ktot;
-    // destination-linear so the stores coalesce: dst[(ci*taps + tap)*cout + co] = src[(co*taps + tap)*cin + ci]
-    for (long d = (long)blockIdx.x * 256 + threadIdx.x; d < total; d += (long)gridDim.x * 256) {
-        const int co = (int)(d % cout);
-        const long r = d / cout;
-        const int tap = (int)(r % taps), ci = (int)(r / taps);
-        wt[off + d] = w[off + ((long)co * taps + tap) * cin + ci];
+    const int cout = row[1], taps = row[3], cin = row[4];
+    const int tco = (cout + 31) >> 5, tci = (cin + 31) >> 5;
+    const int ntiles = taps * tco * tci;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tap = t / (tco * tci), r = t - tap * tco * tci;
+        const int co0 = (r / tci) << 5, ci0 = (r % tci) << 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = co0 + ty + 8 * i, ci = ci0 + tx;
+            tile[ty + 8 * i][tx] = (co < cout && ci < cin) ? w[off + ((long)co * taps + tap) * cin + ci] : (unsigned short)0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ci = ci0 + ty + 8 * i, co = co0 + tx;
+            if (ci < cin && co < cout) wt[off + ((long)ci * taps + tap) * cout + co] = tile[tx][ty + 8 * i];
+        }
+        __syncthreads();
     }
 }
 
@@ -111,8 +125,9 @@ extern "C" int fn_adam_tick(float* hyper, float beta1, float beta2, void* stream
 extern "C" int fn_pack_transpose(const void* w_lp, void* wt_lp, const int32_t* table, int n_layers, int max_layer_elems, int dtype, void* stream) {
     FN_REQUIRE(dtype == FN_BF16 || dtype == FN_F16, "dtype %d unsupported", dtype);
     FN_REQUIRE(w_lp && wt_lp && table && n_layers > 0 && max_layer_elems > 0, "pack_transpose: bad arguments");
-    int gx = cdiv(max_layer_elems, 256 * 8);
-    if (gx > 256) gx = 256;
+    int gx = cdiv(max_layer_elems, 1024 * 4);
+    if (gx > 128) gx = 128;
+    if (gx < 1) gx = 1;
     hipLaunchKernelGGL(pack_transpose_kernel<__bf16>, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)w_lp,
                        (unsigned short*)wt_lp, table);  // pure 16-bit moves: one instantiation serves both dtypes
     return check_launch("pack_transpose");

@@ -43,6 +43,41 @@ class GraphRunner:
         return g
 
 
+def group_wgrads(ops: List[Op], net: Network) -> List[Op]:
+    """Weight gradients have no consumer before the optimiser (or the bucket all-reduce): pull every ``conv_wgrad`` launch
+    out of ``ops`` and append ONE grouped launch per tile variant at the end (fn_conv2d_wgrad_grouped), planned once on the
+    host.  Thousands of workgroups per launch instead of ~130 launches that each fill a fraction of the 256 CUs."""
+    lib = net.lib
+    singles = [op for op in ops if op.name.startswith("conv_wgrad:") and op.keep]
+    if len(singles) < 2:
+        return list(ops)
+    rest = [op for op in ops if not (op.name.startswith("conv_wgrad:") and op.keep)]
+    groups = {}
+    for op in singles:
+        d = op.keep[0]
+        groups.setdefault((lib.fn_conv2d_variant(C.byref(d), 2), d.dtype), []).append(op)
+    nbytes = lib.fn_conv2d_wgrad_arg_bytes()
+    out = list(rest)
+    for (variant, dt), members in sorted(groups.items()):
+        n = len(members)
+        descs = (_lib.ConvDesc * n)(*[m.keep[0] for m in members])
+        host_args = (C.c_uint8 * (nbytes * n))()
+        host_prefix = (C.c_int32 * (n + 1))()
+        total = lib.fn_conv2d_wgrad_group_build(descs, n, variant, host_args, host_prefix)
+        if total < 0:
+            _lib.check(total, "wgrad_group_build")
+        dev_args = torch.frombuffer(bytearray(host_args), dtype=torch.uint8).to(net.device)
+        dev_prefix = torch.tensor(list(host_prefix), dtype=torch.int32, device=net.device)
+        reads, writes = [], []
+        for m in members:
+            reads.extend(m.reads)
+            writes.extend(m.writes)
+        out.append(Op(f"conv_wgrad_grouped:{variant // 1000}x{variant % 1000}", lib.fn_conv2d_wgrad_grouped,
+                      (_ptr(dev_args), _ptr(dev_prefix), n, total, variant, dt), keep=(descs, dev_args, dev_prefix, members),
+                      reads=tuple(reads), writes=tuple(writes)))
+    return out
+
+
 def _streams_for(net: Network, n_streams: int) -> StreamSet:
     ss = getattr(net, "_stream_set", None)
     if ss is None or len(ss.side) < n_streams - 1:
@@ -54,7 +89,8 @@ def _streams_for(net: Network, n_streams: int) -> StreamSet:
 class Trainer:
     def __init__(self, net: Network, batch: int, loss: str = "triplet", alpha: float = 0.2, lr: float = 0.05, beta1: float = 0.9,
                  beta2: float = 0.999, epsilon: float = 0.1, l2: float = L2_WEIGHT, world_size: int = 1, process_group=None,
-                 n_buckets: int = 6, n_streams: int = 2):
+                 n_buckets: int = 6, n_streams: int = 2, group_wgrad: bool = True):
+        self.group_wgrad = group_wgrad
         if loss not in ("triplet", "softmax"):
             raise ValueError(f"unknown loss {loss!r}")
         if loss == "triplet" and batch % 3:
@@ -172,18 +208,28 @@ class Trainer:
         complete; every segment is its own multi-stream schedule (all streams joined at its end), and the bucket's
         all-reduce is issued on the communication stream while the next segment computes."""
         head = self.pre_ops + self.plan.fwd + self.loss_ops
+        grp = (lambda ops: group_wgrads(ops, self.net)) if self.group_wgrad else (lambda ops: list(ops))
         self.segments: List[Tuple[Optional[Schedule], Optional[Tuple[int, int]]]] = []
         if self.world == 1:
-            self.segments.append((Schedule(head + self.plan.bwd + self.opt_ops, self.n_streams), None))
+            self.segments.append((Schedule(grp(head + self.plan.bwd) + self.opt_ops, self.n_streams), None))
             return
         pos, first = 0, True
         for (ready, lo, hi) in self.buckets:
             a, b = pos, max(pos, ready)
-            ops = (head if first else []) + self.plan.bwd[a:b]
+            ops = grp((head if first else []) + self.plan.bwd[a:b])   # a bucket's weight gradients stay inside its segment
             self.segments.append((Schedule(ops, self.n_streams) if ops else None, (lo, hi)))
             pos, first = b, False
         assert pos == len(self.plan.bwd)
         self.segments.append((Schedule(self.opt_ops, 1), None))
+
+    @property
+    def step_ops(self) -> List[Op]:
+        """The launches one step actually issues, in program order (after weight-gradient grouping)."""
+        out: List[Op] = []
+        for sched, _ in self.segments:
+            if sched is not None:
+                out.extend(sched.ops)
+        return out
 
     # ---- one step ------------------------------------------------------------------------------
     def _zero(self):

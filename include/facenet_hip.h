@@ -61,6 +61,13 @@ typedef struct fn_conv_desc {
 int fn_conv2d_fwd(const fn_conv_desc* d, void* stream);
 int fn_conv2d_dgrad(const fn_conv_desc* d, void* stream);
 int fn_conv2d_wgrad(const fn_conv_desc* d, void* stream);
+/* Grouped weight gradients: one launch for many layers that share a tile variant (= fn_conv2d_variant(d, 2)).
+ * fn_conv2d_wgrad_group_build plans on the HOST: it fills host_args (n * fn_conv2d_wgrad_arg_bytes() bytes, opaque) and
+ * host_prefix (n+1 workgroup offsets) and returns the total workgroup count; the caller copies both to device memory once and
+ * replays fn_conv2d_wgrad_grouped every step (pointers inside the descriptors must stay valid). */
+int fn_conv2d_wgrad_arg_bytes(void);
+int fn_conv2d_wgrad_group_build(const fn_conv_desc* descs, int n, int variant, void* host_args, int32_t* host_prefix);
+int fn_conv2d_wgrad_grouped(const void* dev_args, const int32_t* dev_prefix, int n, int total_blocks, int variant, int dtype, void* stream);
 /* tile variant the descriptor dispatches to (op 0 fwd, 1 dgrad, 2 wgrad): BM*1000+BN; measurement aid only */
 int fn_conv2d_variant(const fn_conv_desc* d, int op);
 

@@ -145,3 +145,44 @@ def test_conv_rejects_bad_geometry(lib):
     d.x = d.w = d.y = ptr(x)
     with pytest.raises(ValueError):
         _lib.check(lib.fn_conv2d_fwd(C.byref(d), stream()))
+
+
+def test_conv_wgrad_grouped_matches_single_launches(lib):
+    """fn_conv2d_wgrad_grouped: several layers of one tile variant in ONE launch == the per-layer launches."""
+    dt = _lib.FN_BF16
+    cases = [(3, 8, 8, 128, 128, 1, 7, 1, 0, 3), (3, 8, 8, 896, 128, 1, 1, 1, 0, 0), (2, 17, 17, 192, 192, 3, 3, 1, 1, 1),
+             (5, 3, 3, 192, 192, 3, 1, 1, 1, 0), (2, 17, 17, 192, 256, 3, 3, 2, 0, 0)]
+    descs, keep, singles = [], [], []
+    for i, (N, H, W, Cin, Cout, kh, kw, s, ph, pw) in enumerate(cases):
+        d = conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt)
+        x = _mk((N, H, W, Cin), dt, seed=31 + i)
+        dy = _mk((N, d.OH, d.OW, Cout), dt, seed=41 + i)
+        dw = torch.zeros(Cout, kh, kw, Cin, dtype=torch.float32, device="cuda")
+        ref = torch.zeros_like(dw)
+        d.x, d.y, d.dw = ptr(x), ptr(dy), ptr(ref)
+        _lib.check(lib.fn_conv2d_wgrad(C.byref(d), stream()))
+        d.dw = ptr(dw)
+        descs.append(d); keep.append((x, dy, dw, ref))
+    groups = {}
+    for d, k in zip(descs, keep):
+        groups.setdefault(lib.fn_conv2d_variant(C.byref(d), 2), []).append((d, k))
+    assert len(groups) >= 1
+    nbytes = lib.fn_conv2d_wgrad_arg_bytes()
+    for variant, members in groups.items():
+        n = len(members)
+        arr = (_lib.ConvDesc * n)(*[m[0] for m in members])
+        host_args = (C.c_uint8 * (nbytes * n))()
+        host_prefix = (C.c_int32 * (n + 1))()
+        total = lib.fn_conv2d_wgrad_group_build(arr, n, variant, host_args, host_prefix)
+        assert total > 0 and list(host_prefix)[0] == 0 and list(host_prefix)[-1] == total
+        dev_args = torch.frombuffer(bytearray(host_args), dtype=torch.uint8).cuda()
+        dev_prefix = torch.tensor(list(host_prefix), dtype=torch.int32, device="cuda")
+        _lib.check(lib.fn_conv2d_wgrad_grouped(ptr(dev_args), ptr(dev_prefix), n, total, variant, dt, stream()))
+    torch.cuda.synchronize()
+    for (x, dy, dw, ref) in keep:
+        assert rel_err(dw, ref) < 2e-5
+    # a descriptor of another variant is rejected
+    bad = (_lib.ConvDesc * 1)(descs[0])
+    other = [v for v in (32064, 64064, 128128) if v != lib.fn_conv2d_variant(C.byref(descs[0]), 2)][0]
+    with pytest.raises(ValueError):
+        _lib.check(lib.fn_conv2d_wgrad_group_build(bad, 1, other, (C.c_uint8 * nbytes)(), (C.c_int32 * 2)()))
