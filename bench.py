@@ -64,7 +64,7 @@ def pmc_traffic(kernel_key):
     profiles/r01_pmc_hbm_traffic.json); None when the profile is absent."""
     import re
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    m = re.match(r"(conv_igemm_kernel|conv_wgrad_kernel|conv_wgrad_grouped_kernel)<(__bf16|_Float16),(\d+),(\d+)>", kernel_key)
+    m = re.match(r"(conv_igemm_kernel|conv_igemm_grouped_kernel|conv_wgrad_kernel|conv_wgrad_grouped_kernel)<(__bf16|_Float16),(\d+),(\d+)>", kernel_key)
     if not (m and os.path.exists(path)):
         return None
     pat = f"{m.group(1)}I{'DF16b' if m.group(2) == '__bf16' else 'DF16_'}Li{m.group(3)}ELi{m.group(4)}E"
@@ -89,7 +89,17 @@ def kernel_roofline(trainer, miner, lib, dump=None):
     per_op = []
     for op, ms in zip(all_ops, t):
         kind = op.name.split(":")[0]
-        if kind == "conv_wgrad_grouped":
+        if kind in ("conv_fwd_grouped", "conv_dgrad_grouped"):
+            descs = op.keep[0]
+            opi = 0 if kind == "conv_fwd_grouped" else 1
+            tname = "__bf16" if descs[0].dtype == 0 else "_Float16"
+            key = f"conv_igemm_grouped_kernel<{tname},{op.name.split(':')[1].replace('x', ',')}>"
+            fl = sum(conv_flops(d, opi) for d in descs)
+            g = groups.setdefault(key, dict(ms=0.0, flops=0.0, launches=0, bound="mfma"))
+            g["flops"] += fl
+            per_op.append(dict(op=op.name, kernel=key, us=round(ms * 1e3, 2), gflop=round(fl / 1e9, 3), layers=len(descs),
+                               tflops=round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0))
+        elif kind == "conv_wgrad_grouped":
             descs = op.keep[0]
             tname = "__bf16" if descs[0].dtype == 0 else "_Float16"
             key = f"conv_wgrad_grouped_kernel<{tname},{op.name.split(':')[1].replace('x', ',')}>"

@@ -64,7 +64,7 @@ __device__ __forceinline__ int ktab_entry(int kgroup, int KTOT, int CS, int KW) 
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid) {
     constexpr int BK = 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MREP = TM / 16, NREP = TN / 16;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int tile = xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n);
+    const int tile = xcd_remap(bid, a.tiles_m * a.tiles_n);
     const int tm = tile / a.tiles_n, tn = tile - tm * a.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int ntiles_k = (a.KTOT + BK - 1) / BK;
@@ -326,14 +326,45 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+    conv_igemm_body<T, BM, BN, WM, WN, DEPTH, PLAIN>(a, blockIdx.x);
+}
+
+// Grouped form: one launch runs several INDEPENDENT convolutions of one tile variant (sibling inception towers, the
+// same dependency level of the launch list): args[g] is layer g, prefix[g] .. prefix[g+1] its workgroups.
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN>
+__global__ __launch_bounds__(256) void conv_igemm_grouped_kernel(const ConvArgs* __restrict__ args, const int* __restrict__ prefix, int n) {
+    const int bid = blockIdx.x;
+    int g = 0;
+    while (g + 1 < n && prefix[g + 1] <= bid) ++g;     // n is small (<= 8)
+    const ConvArgs a = args[g];
+    conv_igemm_body<T, BM, BN, WM, WN, DEPTH, PLAIN>(a, bid - prefix[g]);
+}
+
+static size_t conv_smem_bytes(int BM, int BN, int KTOT) {
+    const int STAGE = 2 * (BM * 128 + BN * 128);
+    const int CB = BM * (BN + 4) * 4;
+    return (size_t)(STAGE > CB ? STAGE : CB) + 2 * BN * 4 + (size_t)cdiv(KTOT, 64) * 8 * 4;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN>
+static int launch_conv_grouped_p(const ConvArgs* dev_args, const int32_t* dev_prefix, int n, int total, size_t smem, hipStream_t st) {
+    auto kern = conv_igemm_grouped_kernel<T, BM, BN, WM, WN, DEPTH, PLAIN>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(total), dim3(256), smem, st, dev_args, dev_prefix, n);
+    return check_launch("conv_igemm_grouped");
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN>
 static int launch_conv_p(const ConvArgs& a0, hipStream_t st) {
     ConvArgs a = a0;
     a.tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.NOUT, BN);
-    constexpr int STAGE = 2 * (BM * 128 + BN * 128);
-    constexpr int CB = BM * (BN + 4) * 4;
-    const int ntk = cdiv(a.KTOT, 64);
-    const size_t smem = (STAGE > CB ? STAGE : CB) + 2 * BN * 4 + (size_t)ntk * 8 * 4;
+    const size_t smem = conv_smem_bytes(BM, BN, a.KTOT);
     if (smem > 160 * 1024) {
         set_error("conv: K=%d needs %zu B of LDS (>160 KiB)", a.KTOT, smem);
         return FN_EUNSUPPORTED;
@@ -370,35 +401,36 @@ static void choose_conv_tile(int M, int NOUT, int& bm, int& bn) {
     while (bm == 32 && bn > 32 && (long)cdiv(M, 32) * cdiv(NOUT, bn) < 384) bn >>= 1;
 }
 
+// the nine tile variants: BM, BN, waves (M x N), register stages
+#define FN_CONV_VARIANTS(X) X(128, 128, 2, 2, 1) X(128, 64, 2, 2, 1) X(128, 32, 4, 1, 1) X(64, 128, 1, 4, 2) X(64, 64, 2, 2, 2) \
+    X(64, 32, 2, 2, 2) X(32, 128, 1, 4, 4) X(32, 64, 1, 4, 4) X(32, 32, 2, 2, 4)
+
 template <typename T> static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     int bm, bn;
     choose_conv_tile(a.M, a.NOUT, bm, bn);
-    if (const char* f = getenv("FN_CONV_TILE")) {   // tuning aid: "BMxBNxDEPTH"
-        int fm = 0, fnn = 0, fd = 0;
-        if (sscanf(f, "%dx%dx%d", &fm, &fnn, &fd) == 3) {
-            if (fm == 64 && fnn == 128 && fd == 4) return launch_conv<T, 64, 128, 1, 4, 4>(a, st);
-            if (fm == 64 && fnn == 64 && fd == 4) return launch_conv<T, 64, 64, 2, 2, 4>(a, st);
-            if (fm == 64 && fnn == 32 && fd == 4) return launch_conv<T, 64, 32, 2, 2, 4>(a, st);
-            if (fm == 64 && fnn == 128 && fd == 1) return launch_conv<T, 64, 128, 1, 4, 1>(a, st);
-            if (fm == 64 && fnn == 64 && fd == 1) return launch_conv<T, 64, 64, 2, 2, 1>(a, st);
-            if (fm == 128 && fnn == 128 && fd == 2) return launch_conv<T, 128, 128, 2, 2, 2>(a, st);
-            if (fm == 128 && fnn == 64 && fd == 2) return launch_conv<T, 128, 64, 2, 2, 2>(a, st);
-            bm = fm; bn = fnn;
-        }
+    if (const char* f = getenv("FN_CONV_TILE")) {   // tuning aid: "BMxBN"
+        int fm = 0, fnn = 0;
+        if (sscanf(f, "%dx%d", &fm, &fnn) == 2) { bm = fm; bn = fnn; }
     }
-    if (bm == 128) {
-        if (bn == 128) return launch_conv<T, 128, 128, 2, 2, 1>(a, st);
-        if (bn == 64) return launch_conv<T, 128, 64, 2, 2, 1>(a, st);
-        return launch_conv<T, 128, 32, 4, 1, 1>(a, st);
-    }
-    if (bm == 64) {
-        if (bn == 128) return launch_conv<T, 64, 128, 1, 4, 2>(a, st);
-        if (bn == 64) return launch_conv<T, 64, 64, 2, 2, 2>(a, st);
-        return launch_conv<T, 64, 32, 2, 2, 2>(a, st);
-    }
-    if (bn == 128) return launch_conv<T, 32, 128, 1, 4, 4>(a, st);
-    if (bn == 64) return launch_conv<T, 32, 64, 1, 4, 4>(a, st);
-    return launch_conv<T, 32, 32, 2, 2, 4>(a, st);
+#define FN_X(BM_, BN_, WM_, WN_, D_) \
+    if (bm == BM_ && bn == BN_) return launch_conv<T, BM_, BN_, WM_, WN_, D_>(a, st);
+    FN_CONV_VARIANTS(FN_X)
+#undef FN_X
+    set_error("conv: no tile variant %dx%d", bm, bn);
+    return FN_EUNSUPPORTED;
+}
+
+template <typename T>
+static int dispatch_conv_grouped(const ConvArgs* dev_args, const int32_t* dev_prefix, int n, int total, int bm, int bn, int plain, size_t smem,
+                                 hipStream_t st) {
+#define FN_X(BM_, BN_, WM_, WN_, D_)                                                                                                  \
+    if (bm == BM_ && bn == BN_)                                                                                                       \
+        return plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, true>(dev_args, dev_prefix, n, total, smem, st)               \
+                     : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, false>(dev_args, dev_prefix, n, total, smem, st);
+    FN_CONV_VARIANTS(FN_X)
+#undef FN_X
+    set_error("conv_grouped: no tile variant %dx%d", bm, bn);
+    return FN_EUNSUPPORTED;
 }
 
 static int check_desc(const fn_conv_desc* d) {
@@ -658,8 +690,10 @@ static int choose_wgrad_splits(int M, int Cout, int KTOT, int bmw, int bnw) {
 
 static void final_wgrad_tile(int Cout, int KTOT, int& bmw, int& bnw) {
     choose_wgrad_tile(Cout, KTOT, bmw, bnw);
+    static const int big = getenv("FN_WGRAD_BIG") ? atoi(getenv("FN_WGRAD_BIG")) : 0;   // tuning aid
+    if (big == 1) return;
     // small problems: prefer 64-wide tiles so that enough workgroups exist without a deep split
-    if ((long)cdiv(KTOT, bnw) * cdiv(Cout, bmw) < 64) {
+    if ((long)cdiv(KTOT, bnw) * cdiv(Cout, bmw) < (big == 2 ? 16 : 64)) {
         if (bmw == 128) bmw = 64;
         if (bnw == 128 && KTOT > 64) bnw = 64;
     }
@@ -693,12 +727,12 @@ template <typename T> static int dispatch_wgrad(WgradArgs& a, int want_splits, h
 
 using namespace fn;
 
-extern "C" int fn_conv2d_fwd(const fn_conv_desc* d, void* stream) {
+static int make_fwd_args(const fn_conv_desc* d, ConvArgs& a) {
     if (int rc = check_desc(d)) return rc;
     FN_REQUIRE(d->x && d->w && d->y, "conv_fwd: null x/w/y");
     FN_REQUIRE(d->ld_y >= d->Cout && (d->out_f32 ? d->ld_y % 4 == 0 : d->ld_y % 8 == 0), "conv_fwd: ld_y=%d invalid", d->ld_y);
     FN_REQUIRE(!d->resid || d->ld_res % 8 == 0, "conv_fwd: ld_res=%d invalid", d->ld_res);
-    ConvArgs a{};
+    a = ConvArgs{};
     a.src = (const unsigned short*)d->x; a.wp = (const unsigned short*)d->w; a.out = d->y;
     a.bias = d->bias; a.stats = d->stats; a.resid = (const unsigned short*)d->resid;
     a.M = d->N * d->OH * d->OW; a.PH = d->OH; a.PW = d->OW; a.SH = d->H; a.SW = d->W; a.CS = d->Cin;
@@ -710,16 +744,16 @@ extern "C" int fn_conv2d_fwd(const fn_conv_desc* d, void* stream) {
     a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0) ? 1 : 0;
     a.stats_replicas = d->stats_replicas > 0 ? d->stats_replicas : 1;
     a.stats_rep_stride = d->stats_rep_stride;
-    return d->dtype == FN_BF16 ? dispatch_conv<__bf16>(a, (hipStream_t)stream) : dispatch_conv<_Float16>(a, (hipStream_t)stream);
+    return FN_OK;
 }
 
 // dX[n,iy,ix,ci] = sum_{ky,kx,co} dY[n,(iy+pad-ky)/s,(ix+pad-kx)/s,co] * Wt[ci][ky,kx][co]
-extern "C" int fn_conv2d_dgrad(const fn_conv_desc* d, void* stream) {
+static int make_dgrad_args(const fn_conv_desc* d, ConvArgs& a) {
     if (int rc = check_desc(d)) return rc;
     FN_REQUIRE(d->y && d->w && d->dx, "conv_dgrad: null dy/wt/dx");
     FN_REQUIRE(d->Cout % 8 == 0 && d->ld_y % 8 == 0 && d->ld_y >= d->Cout, "conv_dgrad: Cout=%d ld_y=%d must be multiples of 8", d->Cout,
                d->ld_y);
-    ConvArgs a{};
+    a = ConvArgs{};
     a.src = (const unsigned short*)d->y; a.wp = (const unsigned short*)d->w; a.out = d->dx;
     a.M = d->N * d->H * d->W; a.PH = d->H; a.PW = d->W; a.SH = d->OH; a.SW = d->OW; a.CS = d->Cout;
     a.NOUT = d->Cin; a.KTOT = d->KH * d->KW * d->Cout; a.KH = d->KH; a.KW = d->KW;
@@ -727,7 +761,66 @@ extern "C" int fn_conv2d_dgrad(const fn_conv_desc* d, void* stream) {
     a.ld_src = d->ld_y; a.ld_out = d->ld_x; a.ld_res = 0;
     a.relu = 0; a.accumulate = d->accumulate; a.out_f32 = d->out_f32; a.scale = 1.f;
     a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0) ? 1 : 0;
+    a.stats_replicas = 1;
+    return FN_OK;
+}
+
+extern "C" int fn_conv2d_fwd(const fn_conv_desc* d, void* stream) {
+    ConvArgs a;
+    if (int rc = make_fwd_args(d, a)) return rc;
     return d->dtype == FN_BF16 ? dispatch_conv<__bf16>(a, (hipStream_t)stream) : dispatch_conv<_Float16>(a, (hipStream_t)stream);
+}
+
+extern "C" int fn_conv2d_dgrad(const fn_conv_desc* d, void* stream) {
+    ConvArgs a;
+    if (int rc = make_dgrad_args(d, a)) return rc;
+    return d->dtype == FN_BF16 ? dispatch_conv<__bf16>(a, (hipStream_t)stream) : dispatch_conv<_Float16>(a, (hipStream_t)stream);
+}
+
+// ---- grouped forward / data-gradient convolutions -----------------------------------------------------------------------
+extern "C" int fn_conv2d_arg_bytes(void) { return (int)sizeof(ConvArgs); }
+
+// Host-side planning for n INDEPENDENT descriptors (op 0 = fwd, 1 = dgrad) that share tile `variant`
+// (= fn_conv2d_variant(desc, op)) and 1x1-ness: fills host_args / host_prefix, *smem_bytes; returns total workgroups.
+extern "C" int fn_conv2d_group_build(const fn_conv_desc* descs, int n, int op, int variant, void* host_args, int32_t* host_prefix,
+                                     int32_t* smem_bytes) {
+    FN_REQUIRE(descs && host_args && host_prefix && smem_bytes && n > 0 && (op == 0 || op == 1), "conv_group_build: bad arguments");
+    const int bm = variant / 1000, bn = variant % 1000;
+    ConvArgs* out = reinterpret_cast<ConvArgs*>(host_args);
+    long total = 0;
+    size_t smem = 0;
+    int plain0 = -1;
+    for (int i = 0; i < n; ++i) {
+        ConvArgs a;
+        if (int rc = (op == 0 ? make_fwd_args(&descs[i], a) : make_dgrad_args(&descs[i], a))) return rc;
+        int m, k;
+        choose_conv_tile(a.M, a.NOUT, m, k);
+        FN_REQUIRE(m == bm && k == bn, "conv_group_build: descriptor %d dispatches to %dx%d, group is %dx%d", i, m, k, bm, bn);
+        FN_REQUIRE(descs[i].dtype == descs[0].dtype, "conv_group_build: mixed dtypes");
+        if (plain0 < 0) plain0 = a.plain;
+        FN_REQUIRE(a.plain == plain0, "conv_group_build: 1x1 and general convolutions cannot share a group");
+        a.tiles_m = cdiv(a.M, bm);
+        a.tiles_n = cdiv(a.NOUT, bn);
+        host_prefix[i] = (int32_t)total;
+        total += (long)a.tiles_m * a.tiles_n;
+        const size_t sm = conv_smem_bytes(bm, bn, a.KTOT);
+        if (sm > smem) smem = sm;
+        out[i] = a;
+    }
+    FN_REQUIRE(total < (1L << 30) && smem <= 160 * 1024, "conv_group_build: group too large");
+    host_prefix[n] = (int32_t)total;
+    *smem_bytes = (int32_t)smem;
+    return (int)total;
+}
+
+extern "C" int fn_conv2d_grouped(const void* dev_args, const int32_t* dev_prefix, int n, int total_blocks, int variant, int plain,
+                                 int smem_bytes, int dtype, void* stream) {
+    FN_REQUIRE(dev_args && dev_prefix && n > 0 && n <= 64 && total_blocks > 0, "conv_grouped: bad arguments");
+    FN_REQUIRE(dtype == FN_BF16 || dtype == FN_F16, "dtype %d unsupported", dtype);
+    const ConvArgs* a = reinterpret_cast<const ConvArgs*>(dev_args);
+    return dtype == FN_BF16
+               ? dispatch_conv_grouped<__bf16>(a, dev_prefix, n, total_blocks, variant / 1000, variant % 1000, plain, (size_t)smem_bytes, (hipStream_t)stream)
+               : dispatch_conv_grouped<_Float16>(a, dev_prefix, n, total_blocks, variant / 1000, variant % 1000, plain, (size_t)smem_bytes, (hipStream_t)stream);
 }
 
 static int make_wgrad_args(const fn_conv_desc* d, WgradArgs& a) {

@@ -67,6 +67,26 @@ class _Tracker:
         self.r[b] = [(l, h, o) for (l, h, o) in self.r.get(b, []) if not (lo <= l and h <= hi)]
 
 
+def levelize(ops: Sequence[Op]) -> List[int]:
+    """ASAP dependency level of every launch (level = 1 + max level of what it depends on).  Launches of one level are
+    mutually independent, so they may be reordered among themselves or fused into one grouped launch."""
+    tr = _Tracker()
+    level: List[int] = []
+    for i, op in enumerate(ops):
+        deps = set()
+        for rg in op.reads:
+            deps.update(tr.deps_for_read(rg))
+        for rg in op.writes:
+            deps.update(tr.deps_for_write(rg))
+        deps.discard(i)
+        level.append(1 + max((level[d] for d in deps), default=0))
+        for rg in op.reads:
+            tr.note_read(rg, i)
+        for rg in op.writes:
+            tr.note_write(rg, i)
+    return level
+
+
 class Schedule:
     """Placement of ``ops`` on ``n_streams`` streams.  steps = [('wait', stream, event) | ('run', stream, op_index) |
     ('record', stream, event)]; stream 0 is the caller's (capture) stream and everything is joined back to it."""

@@ -61,6 +61,12 @@ typedef struct fn_conv_desc {
 int fn_conv2d_fwd(const fn_conv_desc* d, void* stream);
 int fn_conv2d_dgrad(const fn_conv_desc* d, void* stream);
 int fn_conv2d_wgrad(const fn_conv_desc* d, void* stream);
+/* Grouped forward / data-gradient convolutions: one launch for n INDEPENDENT layers that share a tile variant
+ * (= fn_conv2d_variant(d, op)) and 1x1-ness (plain).  Planned on the host like the grouped weight gradients below. */
+int fn_conv2d_arg_bytes(void);
+int fn_conv2d_group_build(const fn_conv_desc* descs, int n, int op, int variant, void* host_args, int32_t* host_prefix, int32_t* smem_bytes);
+int fn_conv2d_grouped(const void* dev_args, const int32_t* dev_prefix, int n, int total_blocks, int variant, int plain, int smem_bytes,
+                      int dtype, void* stream);
 /* Grouped weight gradients: one launch for many layers that share a tile variant (= fn_conv2d_variant(d, 2)).
  * fn_conv2d_wgrad_group_build plans on the HOST: it fills host_args (n * fn_conv2d_wgrad_arg_bytes() bytes, opaque) and
  * host_prefix (n+1 workgroup offsets) and returns the total workgroup count; the caller copies both to device memory once and

@@ -85,3 +85,19 @@ def test_single_stream_is_program_order():
     s = Schedule(ops, 1)
     assert [x for k, _, x in s.steps if k == "run"] == list(range(40))
     assert s.n_events == 0
+
+
+def test_levelize_gives_a_valid_topological_order():
+    from facenet_amd.schedule import levelize
+    ops = _random_program(150, 8, 11)
+    lv = levelize(ops)
+    for j in range(len(ops)):
+        for i in range(j):
+            if _conflicts(ops[i], ops[j]):
+                assert lv[j] > lv[i]                      # dependent launches are on strictly later levels
+    order = sorted(range(len(ops)), key=lambda i: (lv[i], i))
+    pos = {i: k for k, i in enumerate(order)}
+    for j in range(len(ops)):
+        for i in range(j):
+            if _conflicts(ops[i], ops[j]):
+                assert pos[i] < pos[j]
