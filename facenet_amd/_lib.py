@@ -29,6 +29,8 @@ class ConvDesc(C.Structure):
         ("stats_rep_stride", C.c_int32),
         ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("dx", C.c_void_p), ("dw", C.c_void_p),
         ("bias", C.c_void_p), ("stats", C.c_void_p), ("resid", C.c_void_p),
+        ("bn_y", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_beta", C.c_void_p), ("bn_acc", C.c_void_p),
+        ("ld_bn_y", C.c_int32), ("bn_sq_off", C.c_int32), ("bn_replicas", C.c_int32), ("bn_rep_stride", C.c_int32), ("bn_relu", C.c_int32),
     ]
 
 
@@ -54,7 +56,7 @@ _SIGNATURES = {
     "fn_image_normalize_f32": [_p, _p, _p, _i, _i, _i, _i, _p],
     "fn_gather_images": [_p, _p, _p, _i, _i, _p],
     "fn_bn_relu_train_fwd": [_p, _i, _p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p],
-    "fn_bn_relu_train_bwd": [_p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p],
+    "fn_bn_relu_train_bwd": [_p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "fn_maxpool3x3s2_fwd": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "fn_maxpool3x3s2_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "fn_avgpool_fwd": [_p, _p, _i, _i, _i, _i, _p],

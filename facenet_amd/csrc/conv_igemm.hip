@@ -45,6 +45,13 @@ struct ConvArgs {
     int tiles_m, tiles_n;
     int stats_sq_off, stats_replicas, stats_rep_stride;
     int plain;  // 1x1 / stride 1 / no padding: source pixel == output pixel, k == channel
+    // dgrad epilogue: reduction of the BatchNorm backward of the layer whose output gradient this launch produces
+    const unsigned short* bn_y;   // raw forward output of that layer (same pixels / channel slice as `out`)
+    const float* bn_scale;
+    const float* bn_shift;
+    const float* bn_beta;
+    float* bn_acc;                // acc[rep*stride + c] += sum dyh ; acc[rep*stride + sq_off + c] += sum dyh*xhat
+    int ld_bn_y, bn_sq_off, bn_replicas, bn_rep_stride, bn_relu;
 };
 
 // Bijective XCD-aware remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
@@ -254,7 +261,15 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     constexpr int CG = BN / 8, RP = 256 / CG;
     const int cg = tid % CG, rr = tid / CG;
     const int col = n0 + cg * 8;
+    float bq1[8], bq2[8];   // fused BN-backward partial sums of this thread's 8 columns
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bq1[e] = 0.f; bq2[e] = 0.f; }
     if (col < a.NOUT) {
+        float bnsc[8], bnsf[8], bnbt[8];
+        if (a.bn_y) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bnsc[e] = a.bn_scale[col + e]; bnsf[e] = a.bn_shift[col + e]; bnbt[e] = a.bn_beta[col + e]; }
+        }
         float bias[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) bias[e] = (a.bias && col + e < a.NOUT) ? a.bias[col + e] : 0.f;
@@ -279,6 +294,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
                 for (int e = 0; e < 8; ++e) v[e] = rv[e] + a.scale * v[e];
             }
             const long o = (long)m * a.ld_out + col;
+            if (a.bn_y) {   // dgrad only (no resid/relu/f32 here): v is the complete gradient unless accumulating
+                float yy[8], tot[8];
+                unpack8<T>(*reinterpret_cast<const u32x4*>(a.bn_y + (long)m * a.ld_bn_y + col), yy);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    tot[e] = v[e];
+                    const float zf = fmaf(yy[e], bnsc[e], bnsf[e]);
+                    const float gg = (!a.bn_relu || zf > 0.f) ? tot[e] : 0.f;
+                    bq1[e] += gg;
+                    bq2[e] += gg * (zf - bnbt[e]);
+                }
+            }
             if (a.out_f32) {
                 float* op = reinterpret_cast<float*>(a.out) + o;
                 if (full && !a.accumulate) {
@@ -314,6 +341,26 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
                         op[e] = LP<T>::from_f32(a.relu ? fmaxf(x, 0.f) : x);
                     }
                 }
+            }
+        }
+    }
+    if (a.bn_y) {   // fold the RP row lanes through LDS (the C tile is no longer needed), one atomic per column per block
+        __syncthreads();
+        float* sP = reinterpret_cast<float*>(smem);   // [RP][2*BN]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sP[rr * 2 * BN + cg * 8 + e] = bq1[e];
+            sP[rr * 2 * BN + BN + cg * 8 + e] = bq2[e];
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int c = tid < BN ? tid : tid - BN;
+            if (n0 + c < a.NOUT) {
+                float sum = 0.f;
+#pragma unroll 8
+                for (int t = 0; t < RP; ++t) sum += sP[t * 2 * BN + tid];
+                float* ap = a.bn_acc + (long)(tm % a.bn_replicas) * a.bn_rep_stride + (tid < BN ? 0 : a.bn_sq_off);
+                atomicAdd(&ap[n0 + c], sum);
             }
         }
     }
@@ -762,6 +809,13 @@ static int make_dgrad_args(const fn_conv_desc* d, ConvArgs& a) {
     a.relu = 0; a.accumulate = d->accumulate; a.out_f32 = d->out_f32; a.scale = 1.f;
     a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0) ? 1 : 0;
     a.stats_replicas = 1;
+    if (d->bn_y) {
+        FN_REQUIRE(!d->accumulate && !d->out_f32 && d->bn_scale && d->bn_shift && d->bn_beta && d->bn_acc && d->ld_bn_y % 8 == 0,
+                   "conv_dgrad: fused BN reduction needs a sole-writer low-precision dx and all bn_* pointers");
+        a.bn_y = (const unsigned short*)d->bn_y; a.bn_scale = d->bn_scale; a.bn_shift = d->bn_shift; a.bn_beta = d->bn_beta;
+        a.bn_acc = d->bn_acc; a.ld_bn_y = d->ld_bn_y; a.bn_sq_off = d->bn_sq_off;
+        a.bn_replicas = d->bn_replicas > 0 ? d->bn_replicas : 1; a.bn_rep_stride = d->bn_rep_stride; a.bn_relu = d->bn_relu;
+    }
     return FN_OK;
 }
 

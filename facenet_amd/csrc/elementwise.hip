@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const unsigned 
                                                                  const float* __restrict__ beta, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, float* __restrict__ dbeta,
                                                                  float* __restrict__ s2, int relu, int rows_per_block) {
+    // (dbeta, s2) here are the two halves of the accumulator workspace: acc[c] and acc[sq_off + c]
     __shared__ float red[32][2 * 64 + 1];
     const int c0 = blockIdx.y * 64;
     const int ncg = min(8, (C - c0) >> 3);          // 16-B channel groups in this stripe
@@ -229,34 +230,62 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const unsigned 
     }
 }
 
-// pass 2: dy = rstd * (dyh - dbeta/M - xhat * s2/M) for EVERY element (masked ones included), in place over dz
+// pass 2: dy = rstd * (dyh - S1/M - xhat * S2/M) for EVERY element (masked ones included), in place over dz.
+// Grid = (row chunks, 64-channel stripes); S1, S2 = accumulator replicas summed in the prologue; dbeta += S1.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(unsigned short* __restrict__ dz, int ld_d,
                                                                 const unsigned short* __restrict__ y, int ld_y, int M, int C,
                                                                 const float* __restrict__ beta, const float* __restrict__ scale,
-                                                                const float* __restrict__ shift, const float* __restrict__ dbeta,
-                                                                const float* __restrict__ s2, int relu) {
-    extern __shared__ __attribute__((aligned(16))) float sh[];  // k1[C], k2[C], sc[C], sf[C], bt[C]
-    float* k1 = sh; float* k2 = sh + C; float* sc = sh + 2 * C; float* sf = sh + 3 * C; float* bt = sh + 4 * C;
-    const float invM = 1.f / (float)M;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        k1[c] = dbeta[c] * invM; k2[c] = s2[c] * invM; sc[c] = scale[c]; sf[c] = shift[c]; bt[c] = beta[c];
+                                                                const float* __restrict__ shift, float* __restrict__ dbeta,
+                                                                const float* __restrict__ acc, int sq_off, int reps, int rep_stride,
+                                                                int relu, int rows_per_block) {
+    __shared__ float s_k1[64], s_k2[64], s_part[4][2][64];
+    const int c0 = blockIdx.y * 64;
+    {
+        const int cc = threadIdx.x & 63, q = threadIdx.x >> 6;
+        float s1 = 0.f, s2v = 0.f;
+        if (c0 + cc < C) {
+#pragma unroll 4
+            for (int rp = q; rp < reps; rp += 4) {
+                s1 += acc[(long)rp * rep_stride + c0 + cc];
+                s2v += acc[(long)rp * rep_stride + sq_off + c0 + cc];
+            }
+        }
+        s_part[q][0][cc] = s1;
+        s_part[q][1][cc] = s2v;
     }
     __syncthreads();
-    const int CG = C >> 3;
-    const long total = (long)M * CG;
-    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-        const int row = (int)(t / CG), cg = (int)(t - (long)row * CG);
-        unsigned short* p = dz + (long)row * ld_d + cg * 8;
+    if (threadIdx.x < 64 && c0 + threadIdx.x < C) {
+        const float s1 = s_part[0][0][threadIdx.x] + s_part[1][0][threadIdx.x] + s_part[2][0][threadIdx.x] + s_part[3][0][threadIdx.x];
+        const float s2v = s_part[0][1][threadIdx.x] + s_part[1][1][threadIdx.x] + s_part[2][1][threadIdx.x] + s_part[3][1][threadIdx.x];
+        const float invM = 1.f / (float)M;
+        s_k1[threadIdx.x] = s1 * invM;
+        s_k2[threadIdx.x] = s2v * invM;
+        if (blockIdx.x == 0) dbeta[c0 + threadIdx.x] += s1;
+    }
+    __syncthreads();
+    const int ncg = min(8, (C - c0) >> 3);
+    const int TX = ncg <= 1 ? 1 : (ncg <= 2 ? 2 : (ncg <= 4 ? 4 : 8));
+    const int TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    if (tx >= ncg) return;
+    const int c = c0 + tx * 8;
+    float k1[8], k2[8], sc[8], sf[8], bt[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        k1[e] = s_k1[tx * 8 + e]; k2[e] = s_k2[tx * 8 + e]; sc[e] = scale[c + e]; sf[e] = shift[c + e]; bt[e] = beta[c + e];
+    }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int r = r0 + ty; r < r1; r += TY) {
+        unsigned short* p = dz + (long)r * ld_d + c;
         float g[8], yy[8];
         unpack8<T>(*reinterpret_cast<const u32x4*>(p), g);
-        unpack8<T>(*reinterpret_cast<const u32x4*>(y + (long)row * ld_y + cg * 8), yy);
+        unpack8<T>(*reinterpret_cast<const u32x4*>(y + (long)r * ld_y + c), yy);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int c = cg * 8 + e;
-            const float zf = fmaf(yy[e], sc[c], sf[c]);
+            const float zf = fmaf(yy[e], sc[e], sf[e]);
             const float gg = (!relu || zf > 0.f) ? g[e] : 0.f;
-            g[e] = sc[c] * (gg - k1[c] - (zf - bt[c]) * k2[c]);
+            g[e] = sc[e] * (gg - k1[e] - (zf - bt[e]) * k2[e]);
         }
         *reinterpret_cast<u32x4*>(p) = pack8<T>(g);
     }
@@ -596,16 +625,22 @@ extern "C" int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, 
 }
 
 extern "C" int fn_bn_relu_train_bwd(void* dz, int ld_d, const void* y, int ld_y, int M, int C, const float* beta, const float* save_scale,
-                                    const float* save_shift, float* dbeta, float* s2, int relu, int dtype, void* stream) {
+                                    const float* save_shift, float* dbeta, float* acc, int acc_sq_off, int acc_replicas, int acc_rep_stride,
+                                    int reduced, int relu, int dtype, void* stream) {
     DT_CHECK(dtype);
-    FN_REQUIRE(dz && y && beta && save_scale && save_shift && dbeta && s2 && M > 0 && C > 0 && C % 8 == 0 && ld_d % 8 == 0 &&
+    FN_REQUIRE(dz && y && beta && save_scale && save_shift && dbeta && acc && M > 0 && C > 0 && C % 8 == 0 && ld_d % 8 == 0 &&
                    ld_y % 8 == 0 && C <= 4096, "bn_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    const int rpb = reduce_rows_per_block(M, C);
-    const dim3 g1(cdiv(M, rpb), cdiv(C, 64));
-    const int g2 = grid_for((long)M * (C / 8), 256, 2048);
-    LAUNCH_T(dtype, bn_relu_bwd_reduce_kernel, g1, dim3(256), 0, st, (const unsigned short*)dz, ld_d, (const unsigned short*)y, ld_y, M, C, beta, save_scale, save_shift, dbeta, s2, relu, rpb);
-    LAUNCH_T(dtype, bn_relu_bwd_apply_kernel, dim3(g2), dim3(256), 5 * C * sizeof(float), st, (unsigned short*)dz, ld_d, (const unsigned short*)y, ld_y, M, C, beta, save_scale, save_shift, dbeta, s2, relu);
+    const int reps = acc_replicas > 0 ? acc_replicas : 1;
+    if (!reduced) {
+        const int rpb = reduce_rows_per_block(M, C);
+        const dim3 g1(cdiv(M, rpb), cdiv(C, 64));
+        LAUNCH_T(dtype, bn_relu_bwd_reduce_kernel, g1, dim3(256), 0, st, (const unsigned short*)dz, ld_d, (const unsigned short*)y, ld_y, M, C, beta, save_scale, save_shift, acc, acc + acc_sq_off, relu, rpb);
+    }
+    const int stripes = cdiv(C, 64);
+    int rpb2 = cdiv((long)M * stripes, 2048);
+    if (rpb2 < 32) rpb2 = 32;
+    LAUNCH_T(dtype, bn_relu_bwd_apply_kernel, dim3(cdiv(M, rpb2), stripes), dim3(256), 0, st, (unsigned short*)dz, ld_d, (const unsigned short*)y, ld_y, M, C, beta, save_scale, save_shift, dbeta, acc, acc_sq_off, reps, acc_rep_stride, relu, rpb2);
     return check_launch("bn_relu_bwd");
 }
 

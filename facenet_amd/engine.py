@@ -372,6 +372,7 @@ class Network:
 class Lowering:
     def __init__(self, net: Network, N: int, training: bool, declare: bool, loss: Optional[str] = None):
         self.net, self.N, self.training, self.declare, self.loss = net, N, training, declare, loss
+        self.fuse_bn_bwd = True     # BN-backward reduction inside the producing dgrad's epilogue where it is the sole producer
         self.dtype = net.train_dtype if training else net.infer_dtype
         self.dt = None if declare else _lib.dtype_code(self.dtype)
         self.bufs: "OrderedDict[str, Buf]" = OrderedDict()
@@ -379,6 +380,9 @@ class Lowering:
         self.fwd: List[Op] = []
         self.bwd: List[Op] = []
         self.bwd_marks: List[Tuple[int, int]] = []   # (index into bwd after which..., lowest finished w_off)
+        self.readers: Dict[str, int] = {}            # forward consumers per buffer
+        self.bn_ranges: Dict[str, List[Tuple[int, int, bool]]] = {}
+        self.bn_reduced: Dict[Tuple[str, int, int], int] = {}   # BN slices whose backward reduction a dgrad epilogue performs
         self.embedding = None
 
     # ---- buffers -------------------------------------------------------------------------------
@@ -428,10 +432,15 @@ class Lowering:
         if self.declare and has_bn:
             L.bn_off = out.buf.bn_off + out.c0
         assert out.buf.H == OH and out.buf.W == OW and out.C == cout, name
+        self.readers[x.buf.name] = self.readers.get(x.buf.name, 0) + 1
+        if "trunk" in extra:
+            t = extra["trunk"]
+            self.readers[t.buf.name] = self.readers.get(t.buf.name, 0) + 1
         self.recs.append(Rec("conv", L, x, out, dict(kind=kind, **extra)))
         return out
 
     def bn_apply(self, b: Buf, c0: int, Cc: int, relu: bool = True):
+        self.bn_ranges.setdefault(b.name, []).append((c0, Cc, relu))
         self.recs.append(Rec("bn", None, None, Slice(b, c0, Cc), dict(relu=relu)))
 
     def cbr(self, name, x, cout, k, stride, padding, cin_real=None) -> Slice:
@@ -443,6 +452,7 @@ class Lowering:
         OH, OW = (x.buf.H - 3) // 2 + 1, (x.buf.W - 3) // 2 + 1
         if out is None:
             out = self.buf(name, OH, OW, x.C).full()
+        self.readers[x.buf.name] = self.readers.get(x.buf.name, 0) + 1
         self.recs.append(Rec("maxpool", None, x, out))
         return out
 
@@ -492,6 +502,7 @@ class Lowering:
         if (H // 3, W // 3) != (1, 1):
             raise ValueError(f"head expects a 3x3..5x5 final map (image size 160), got {H}x{W}")  # Flatten ambiguity, hazard 11
         pooled = self.buf("features/avgpool", 1, 1, x.C)
+        self.readers[x.buf.name] = self.readers.get(x.buf.name, 0) + 1
         self.recs.append(Rec("avgpool", None, x, pooled.full()))
         yh = self.buf("features/logits", 1, 1, E, bn_channels=E, f32=True)
         L = self.net._declare_layer("features/logits", x.C, x.C, E, 1, 1, 1, 0, 0, True, False, dense=True) \
@@ -557,6 +568,7 @@ class Lowering:
         if self.training:
             # BN workspace: STAT_REPLICAS x (sum | sumsq) accumulator replicas, then s2 (backward)
             self.ws = torch.zeros((2 * STAT_REPLICAS + 1) * CB, dtype=torch.float32, device=dev)
+            self.ws_b = torch.zeros(2 * STAT_REPLICAS * CB, dtype=torch.float32, device=dev)   # BN-backward sums (replicated)
             self.save_scale = torch.zeros(CB, dtype=torch.float32, device=dev)
             self.save_shift = torch.zeros(CB, dtype=torch.float32, device=dev)
             self.head_mean = torch.zeros(net.E, dtype=torch.float32, device=dev)
@@ -707,8 +719,22 @@ class Lowering:
             g.w = _ptr(net.Wt_train, L.w_off)
             g.dx = _ptr(x.buf.grad, x.c0)
             g.accumulate = self._grad_mode(x)
-            self._emit(self.bwd, "conv_dgrad:" + L.name, lib.fn_conv2d_dgrad, C.byref(g), keep=(g,),
-                       r=[dy_reg, region(net.Wt_train, L.w_off, L.w_off + L.numel)], w=[self._rg(x)])
+            rd = [dy_reg, region(net.Wt_train, L.w_off, L.w_off + L.numel)]
+            wr = [self._rg(x)]
+            bnr = [r_ for r_ in self.bn_ranges.get(x.buf.name, []) if r_[0] == x.c0 and r_[1] == x.C]
+            if self.fuse_bn_bwd and bnr and g.accumulate == 0 and self.readers.get(x.buf.name, 0) == 1 and x.buf.raw is not None:
+                o = x.buf.bn_off + x.c0            # this dgrad is the only producer of d(BN output): reduce in its epilogue
+                reps = self._replicas(x.buf.M)
+                g.bn_y = _ptr(x.buf.raw, x.c0)
+                g.ld_bn_y = x.buf.C
+                g.bn_scale, g.bn_shift = _ptr(self.save_scale, o), _ptr(self.save_shift, o)
+                g.bn_beta = _ptr(net.P, net.beta_base + o)
+                g.bn_acc, g.bn_sq_off, g.bn_replicas, g.bn_rep_stride = _ptr(self.ws_b, o), net.CB, reps, 2 * net.CB
+                g.bn_relu = 1 if bnr[0][2] else 0
+                self.bn_reduced[(x.buf.name, x.c0, x.C)] = reps
+                rd += [self._rr(x), region(self.save_scale, o, o + x.C), region(self.save_shift, o, o + x.C)]
+                wr.append((self.ws_b.data_ptr() + 1, o, o + x.C))
+            self._emit(self.bwd, "conv_dgrad:" + L.name, lib.fn_conv2d_dgrad, C.byref(g), keep=(g,), r=rd, w=wr)
         self._mark(L)
 
     def _bwd_bn(self, r: Rec):
@@ -716,11 +742,12 @@ class Lowering:
         b, c0, Cc = r.y.buf, r.y.c0, r.y.C
         o = b.bn_off + c0
         gb = net.beta_base + o
+        reps = self.bn_reduced.get((b.name, c0, Cc), 0)
         self._emit(self.bwd, "bn_relu_bwd:" + b.name, net.lib.fn_bn_relu_train_bwd, _ptr(b.grad, c0), b.C, _ptr(b.raw, c0), b.C, b.M, Cc,
                    _ptr(net.P, gb), _ptr(self.save_scale, o), _ptr(self.save_shift, o), _ptr(net.G, gb),
-                   _ptr(self.ws, 2 * STAT_REPLICAS * net.CB + o), 1 if r.extra["relu"] else 0, self.dt,
+                   _ptr(self.ws_b, o), net.CB, max(1, reps), 2 * net.CB, 1 if reps else 0, 1 if r.extra["relu"] else 0, self.dt,
                    r=[self._rr(r.y), region(net.P, gb, gb + Cc), region(self.save_scale, o, o + Cc), region(self.save_shift, o, o + Cc)],
-                   w=[self._rg(r.y), region(net.G, gb, gb + Cc), (self.ws.data_ptr() + 2, o, o + Cc)])
+                   w=[self._rg(r.y), region(net.G, gb, gb + Cc), (self.ws_b.data_ptr() + 1, o, o + Cc)])
 
     def _bwd_maxpool(self, r: Rec):
         x, y = r.x, r.y

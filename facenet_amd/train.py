@@ -170,8 +170,9 @@ class Trainer:
         self.emb = emb.view(batch, E)
         self.pre_ops: List[Op] = [
             Op("zero_grads", torch_op(lambda: self.G.zero_()), (), writes=(region(self.G),)),
-            Op("zero_bn_workspace", torch_op(lambda: self.plan.ws.zero_()), (),
-               writes=(region(self.plan.ws), (self.plan.ws.data_ptr() + 1, 0, net.CB), (self.plan.ws.data_ptr() + 2, 0, net.CB))),
+            Op("zero_bn_workspace", torch_op(lambda: (self.plan.ws.zero_(), self.plan.ws_b.zero_())), (),
+               writes=(region(self.plan.ws), (self.plan.ws.data_ptr() + 1, 0, net.CB), region(self.plan.ws_b),
+                       (self.plan.ws_b.data_ptr() + 1, 0, net.CB))),
         ]
         self.loss_ops: List[Op] = []
         if loss == "triplet":
@@ -285,6 +286,7 @@ class Trainer:
     def _zero(self):
         self.G.zero_()
         self.plan.ws.zero_()
+        self.plan.ws_b.zero_()
 
     def _run_segments(self, launch: Callable[[int], None]):
         if self.world == 1:

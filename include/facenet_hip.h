@@ -56,6 +56,14 @@ typedef struct fn_conv_desc {
     const float* bias;         /* fwd: per-Cout fp32 or NULL (BN-folded shift / `up` bias) */
     float* stats;              /* fwd: NULL or fp32: stats[c] += sum, stats[stats_sq_off + c] += sum of squares (BN batch statistics) */
     const void* resid;         /* fwd: residual trunk [N,OH,OW,ld_res] or NULL */
+    /* dgrad: optional fused reduction of the BatchNorm backward of the layer that produced x (see fn_bn_relu_train_bwd):
+     * bn_y = that layer's raw output (same slice as dx), bn_acc[rep*stride + c] += sum dyh, [.. + bn_sq_off + c] += sum dyh*xhat */
+    const void* bn_y;
+    const float* bn_scale;
+    const float* bn_shift;
+    const float* bn_beta;
+    float* bn_acc;
+    int32_t ld_bn_y, bn_sq_off, bn_replicas, bn_rep_stride, bn_relu;
 } fn_conv_desc;
 
 int fn_conv2d_fwd(const fn_conv_desc* d, void* stream);
@@ -96,9 +104,12 @@ int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, int M, int 
                          int relu, int dtype, void* stream);
 /* backward: dz (grad wrt the BN+ReLU output) -> dy (grad wrt the raw conv output y), in place; y is the raw forward
  * conv output (xhat and the ReLU mask are recomputed from it: masked elements still receive the batch-statistic
- * terms).  dbeta[C] (+=) and s2[C] (+=, scratch zeroed by caller) are accumulated by the reduce kernel. */
+ * terms).  acc (zeroed by the caller) holds sum dyh at acc[rep*stride + c] and sum dyh*xhat at acc[rep*stride + acc_sq_off + c];
+ * with reduced = 0 this call fills it (reduce kernel, replica 0), with reduced = 1 a fn_conv2d_dgrad epilogue already did.
+ * dbeta[C] += sum dyh. */
 int fn_bn_relu_train_bwd(void* dz, int ld_d, const void* y, int ld_y, int M, int C, const float* beta, const float* save_scale,
-                         const float* save_shift, float* dbeta, float* s2, int relu, int dtype, void* stream);
+                         const float* save_shift, float* dbeta, float* acc, int acc_sq_off, int acc_replicas, int acc_rep_stride,
+                         int reduced, int relu, int dtype, void* stream);
 
 /* ---- pooling: MaxPool2D(3, strides=2, 'valid') :301,369,409 ; AvgPool2D([3,3]) + Flatten :460-461 */
 int fn_maxpool3x3s2_fwd(const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, int dtype, void* stream);

@@ -186,3 +186,44 @@ def test_conv_wgrad_grouped_matches_single_launches(lib):
     other = [v for v in (32064, 64064, 128128) if v != lib.fn_conv2d_variant(C.byref(descs[0]), 2)][0]
     with pytest.raises(ValueError):
         _lib.check(lib.fn_conv2d_wgrad_group_build(bad, 1, other, (C.c_uint8 * nbytes)(), (C.c_int32 * 2)()))
+
+
+@pytest.mark.parametrize("dt", [_lib.FN_BF16, _lib.FN_F16])
+def test_dgrad_fused_bn_backward_reduction(lib, dt):
+    """dgrad epilogue computing sum(dyh) / sum(dyh*xhat) of the producing layer's BatchNorm (+ReLU) == the standalone
+    reduce kernel; the apply kernel then consumes the replicated accumulators."""
+    N, H, W, Cin, Cout = 3, 17, 17, 64, 96
+    d = conv_desc(N, H, W, Cin, Cout, 3, 3, 1, 1, 1, dt)
+    M = N * H * W
+    dy = _mk((N, H, W, Cout), dt, seed=51)
+    w = _mk((Cout, 3, 3, Cin), dt, 0.1, seed=52)
+    wt = torch.zeros_like(w).view(-1)
+    table = torch.tensor([[0, Cout, 9 * Cin, 9, Cin, -1, -1, 0]], dtype=torch.int32, device="cuda")
+    _lib.check(lib.fn_pack_transpose(ptr(w), ptr(wt), ptr(table), 1, w.numel(), dt, stream()))
+    yraw = _mk((N, H, W, Cin), dt, seed=53, scale=2.0)
+    beta = (torch.randn(Cin, generator=torch.Generator().manual_seed(54)) * 0.3).cuda()
+    yf = yraw.float().view(M, Cin)
+    mean, var = yf.mean(0), yf.var(0, unbiased=False)
+    sc = torch.rsqrt(var + 1e-3).contiguous()
+    sh = (beta - mean * sc).contiguous()
+    reps = 4
+    acc = torch.zeros(reps, 2 * Cin, device="cuda")
+    dx = torch.zeros(N, H, W, Cin, dtype=lp_dtype(dt), device="cuda")
+    d.y, d.w, d.dx = ptr(dy), ptr(wt), ptr(dx)
+    d.bn_y, d.ld_bn_y, d.bn_scale, d.bn_shift, d.bn_beta = ptr(yraw), Cin, ptr(sc), ptr(sh), ptr(beta)
+    d.bn_acc, d.bn_sq_off, d.bn_replicas, d.bn_rep_stride, d.bn_relu = ptr(acc), Cin, reps, 2 * Cin, 1
+    _lib.check(lib.fn_conv2d_dgrad(C.byref(d), stream()))
+    # reference: standalone reduce on the (rounded) dx
+    acc_ref = torch.zeros(2 * Cin, device="cuda")
+    dbeta_ref = torch.zeros(Cin, device="cuda")
+    dx_ref = dx.clone()
+    _lib.check(lib.fn_bn_relu_train_bwd(ptr(dx_ref), Cin, ptr(yraw), Cin, M, Cin, ptr(beta), ptr(sc), ptr(sh), ptr(dbeta_ref), ptr(acc_ref), Cin, 1, 0,
+                                        0, 1, dt, stream()))
+    dbeta = torch.zeros(Cin, device="cuda")
+    _lib.check(lib.fn_bn_relu_train_bwd(ptr(dx), Cin, ptr(yraw), Cin, M, Cin, ptr(beta), ptr(sc), ptr(sh), ptr(dbeta), ptr(acc), Cin, reps, 2 * Cin,
+                                        1, 1, dt, stream()))
+    torch.cuda.synchronize()
+    tol = 2e-2 if dt == _lib.FN_BF16 else 3e-3       # fused sums use the un-rounded fp32 gradient
+    assert rel_err(acc.sum(0), acc_ref) < tol
+    assert rel_err(dbeta, dbeta_ref) < tol
+    assert rel_err(dx, dx_ref) < tol

@@ -64,8 +64,9 @@ def test_bn_relu_train_fwd_bwd(lib, dt, shape):
     dzb = _rand((M, ld), dt, seed=3)
     dref_in = dzb[:, c0:c0 + Cc].float().cpu()
     zr.backward(dref_in)
-    dbeta, s2 = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
-    _lib.check(lib.fn_bn_relu_train_bwd(ptr(dzb, c0), ld, ptr(ybuf, c0), ld, M, Cc, ptr(beta), ptr(sc), ptr(sh), ptr(dbeta), ptr(s2), 1, dt, stream()))
+    dbeta, acc = torch.zeros(Cc, device="cuda"), torch.zeros(2 * Cc, device="cuda")
+    _lib.check(lib.fn_bn_relu_train_bwd(ptr(dzb, c0), ld, ptr(ybuf, c0), ld, M, Cc, ptr(beta), ptr(sc), ptr(sh), ptr(dbeta), ptr(acc), Cc, 1, 0,
+                                        0, 1, dt, stream()))
     torch.cuda.synchronize()
     assert rel_err(dzb[:, c0:c0 + Cc], yr.grad) < (8e-3 if dt == BF else 1e-3)
     dbeta_ref = (dref_in * (zr.detach() > 0)).sum(0)
