@@ -52,6 +52,12 @@ struct ConvArgs {
     const float* bn_beta;
     float* bn_acc;                // acc[rep*stride + c] += sum dyh ; acc[rep*stride + sq_off + c] += sum dyh*xhat
     int ld_bn_y, bn_sq_off, bn_replicas, bn_rep_stride, bn_relu;
+    // stride-2 dgrad: output pixels are split into 4 parity classes ((iy+pad)&1, (ix+pad)&1); a class only sees the taps
+    // of matching parity, so each class is its own GEMM (M = its pixels, K = its taps) inside one launch.
+    int s2;                 // 1 = class mode
+    int cp1, cp2, cp3;      // first tile of classes 1..3 (class 0 starts at 0)
+    int ny0, ny1, ny2, ny3, nx0, nx1, nx2, nx3;   // pixels per image row / column of every class (scalars: no indexing)
+    int total_tiles;
 };
 
 // Bijective XCD-aware remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
@@ -60,6 +66,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
     const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
     return base + (bid >> 3);
+}
+
+// class mode: taps ky in {qy, qy+2, ..}, kx in {qx, qx+2, ..}
+__device__ __forceinline__ int ktab_entry_s2(int kgroup, int CS, int KH, int KW, int qy, int qx) {
+    const int nky = (KH - qy + 1) >> 1, nkx = (KW - qx + 1) >> 1;
+    const int k = kgroup * 8;
+    if (k >= nky * nkx * CS) return -1;
+    const int tap = k / CS, c = k - tap * CS;
+    const int ty = tap / nkx, tx = tap - ty * nkx;
+    return ((qy + 2 * ty) << 24) | ((qx + 2 * tx) << 16) | c;
 }
 
 __device__ __forceinline__ int ktab_entry(int kgroup, int KTOT, int CS, int KW) {
@@ -92,13 +108,35 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int tile = xcd_remap(bid, a.tiles_m * a.tiles_n);
-    const int tm = tile / a.tiles_n, tn = tile - tm * a.tiles_n;
+    int cls = 0, qy = 0, qx = 0, cls_M = a.M, ktot = a.KTOT, tm, tn, cny = 0, cnx = 0;
+    if (!PLAIN && a.s2) {
+        // static indices only: in the grouped kernel `a` lives in registers and a dynamic index would send it to scratch
+        const int t = xcd_remap(bid, a.total_tiles);
+        int cp = 0;
+        cny = a.ny0; cnx = a.nx0;
+        if (t >= a.cp1) { cls = 1; cp = a.cp1; cny = a.ny1; cnx = a.nx1; }
+        if (t >= a.cp2) { cls = 2; cp = a.cp2; cny = a.ny2; cnx = a.nx2; }
+        if (t >= a.cp3) { cls = 3; cp = a.cp3; cny = a.ny3; cnx = a.nx3; }
+        const int lt = t - cp;
+        tm = lt / a.tiles_n;
+        tn = lt - tm * a.tiles_n;
+        qy = cls >> 1;
+        qx = cls & 1;
+        cls_M = (a.M / (a.PH * a.PW)) * cny * cnx;
+        ktot = ((a.KH - qy + 1) >> 1) * ((a.KW - qx + 1) >> 1) * a.CS;
+    } else {
+        const int tile = xcd_remap(bid, a.tiles_m * a.tiles_n);
+        tm = tile / a.tiles_n;
+        tn = tile - tm * a.tiles_n;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int ntiles_k = (a.KTOT + BK - 1) / BK;
+    const int ntiles_k = (ktot + BK - 1) / BK;
+    int* sRow = sK + ((a.KTOT + BK - 1) / BK) * 8;   // [BM] output pixel of every tile row (class mode)
 
-    if constexpr (!PLAIN)
-        for (int i = tid; i < ntiles_k * 8; i += 256) sK[i] = ktab_entry(i, a.KTOT, a.CS, a.KW);
+    if constexpr (!PLAIN) {
+        if (a.s2) for (int i = tid; i < ntiles_k * 8; i += 256) sK[i] = ktab_entry_s2(i, a.CS, a.KH, a.KW, qy, qx);
+        else for (int i = tid; i < ntiles_k * 8; i += 256) sK[i] = ktab_entry(i, a.KTOT, a.CS, a.KW);
+    }
     if (tid < 2 * BN) sRed[tid] = 0.f;
 
     // per-thread gather rows
@@ -111,6 +149,22 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             rowy[i] = (m < a.M) ? 0 : -1;
             rowx[i] = 0;
             rowbase[i] = m;
+        } else if (a.s2) {
+            if (m < cls_M) {
+                const int ny = cny, nx = cnx;
+                const int n = m / (ny * nx), rem = m - n * ny * nx;
+                const int j = rem / nx, ii = rem - j * nx;
+                const int py = 2 * j + ((qy - a.offy) & 1), px = 2 * ii + ((qx - a.offx) & 1);   // (py + pad) & 1 == qy
+                rowy[i] = py + a.offy;
+                rowx[i] = px + a.offx;
+                rowbase[i] = n * a.SH * a.SW;
+                if (kg == 0) sRow[r0 + 32 * i] = (n * a.PH + py) * a.PW + px;
+            } else {
+                rowy[i] = -(1 << 28);
+                rowx[i] = 0;
+                rowbase[i] = 0;
+                if (kg == 0) sRow[r0 + 32 * i] = -1;
+            }
         } else if (m < a.M) {
             const int n = m / (a.PH * a.PW), rem = m - n * a.PH * a.PW;
             const int py = rem / a.PW, px = rem - py * a.PW;
@@ -156,12 +210,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             ra[i] = v;
         }
         }
-        const int k = kt * BK + kg * 8;
+        int k = kt * BK + kg * 8;
+        bool kok = k < ktot;
+        if constexpr (!PLAIN) {
+            const int e2 = sK[kt * 8 + kg];   // weight column of this k group: (ky*KW + kx)*CS + c
+            kok = e2 >= 0;
+            k = ((((e2 >> 24) & 0xff) * a.KW + ((e2 >> 16) & 0xff)) * a.CS) + (e2 & 0xffff);
+        }
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
             const int co = n0 + r0 + 32 * j;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (co < a.NOUT && k < a.KTOT) v = *reinterpret_cast<const u32x4*>(a.wp + (long)co * a.KTOT + k);
+            if (co < a.NOUT && kok) v = *reinterpret_cast<const u32x4*>(a.wp + (long)co * a.KTOT + k);
             rb[j] = v;
         }
     };
@@ -277,8 +337,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 #pragma unroll
         for (int ps = 0; ps < (BM + RP - 1) / RP; ++ps) {
             const int row = ps * RP + rr;
-            const int m = m0 + row;
-            if (row >= BM || m >= a.M) continue;
+            if (row >= BM) continue;
+            int m = m0 + row;
+            if (!PLAIN && a.s2) {
+                m = sRow[row];
+                if (m < 0) continue;
+            } else if (m >= a.M) {
+                continue;
+            }
             float v[8];
             const f32x4 c0 = *reinterpret_cast<const f32x4*>(&sC[row * CLD + cg * 8]);
             const f32x4 c1 = *reinterpret_cast<const f32x4*>(&sC[row * CLD + cg * 8 + 4]);
@@ -384,14 +450,41 @@ __global__ __launch_bounds__(256) void conv_igemm_grouped_kernel(const ConvArgs*
     const int bid = blockIdx.x;
     int g = 0;
     while (g + 1 < n && prefix[g + 1] <= bid) ++g;     // n is small (<= 8)
+    g = __builtin_amdgcn_readfirstlane(g);             // provably wave-uniform: args[g] is fetched with scalar loads into SGPRs
     const ConvArgs a = args[g];
     conv_igemm_body<T, BM, BN, WM, WN, DEPTH, PLAIN>(a, bid - prefix[g]);
+}
+
+// tiles of a launch; in class mode (stride-2 dgrad) every parity class has its own row tiles
+static void plan_tiles(ConvArgs& a, int BM, int BN) {
+    a.tiles_n = cdiv(a.NOUT, BN);
+    if (!a.s2) {
+        a.tiles_m = cdiv(a.M, BM);
+        a.total_tiles = a.tiles_m * a.tiles_n;
+        return;
+    }
+    const int nimg = a.M / (a.PH * a.PW);
+    int ny[4], nx[4], pre[5];
+    int t = 0;
+    for (int c = 0; c < 4; ++c) {
+        const int qy = c >> 1, qx = c & 1;
+        const int y0 = (qy - a.offy) & 1, x0 = (qx - a.offx) & 1;       // first pixel of the class
+        ny[c] = a.PH > y0 ? (a.PH - y0 + 1) / 2 : 0;
+        nx[c] = a.PW > x0 ? (a.PW - x0 + 1) / 2 : 0;
+        pre[c] = t;   // a class without taps still owns pixels: they receive zeros (K = 0) and must be written
+        t += cdiv(nimg * ny[c] * nx[c], BM) * a.tiles_n;
+    }
+    a.cp1 = pre[1]; a.cp2 = pre[2]; a.cp3 = pre[3];
+    a.ny0 = ny[0]; a.ny1 = ny[1]; a.ny2 = ny[2]; a.ny3 = ny[3];
+    a.nx0 = nx[0]; a.nx1 = nx[1]; a.nx2 = nx[2]; a.nx3 = nx[3];
+    a.tiles_m = 0;
+    a.total_tiles = t;
 }
 
 static size_t conv_smem_bytes(int BM, int BN, int KTOT) {
     const int STAGE = 2 * (BM * 128 + BN * 128);
     const int CB = BM * (BN + 4) * 4;
-    return (size_t)(STAGE > CB ? STAGE : CB) + 2 * BN * 4 + (size_t)cdiv(KTOT, 64) * 8 * 4;
+    return (size_t)(STAGE > CB ? STAGE : CB) + 2 * BN * 4 + (size_t)cdiv(KTOT, 64) * 8 * 4 + (size_t)BM * 4;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN>
@@ -409,8 +502,7 @@ static int launch_conv_grouped_p(const ConvArgs* dev_args, const int32_t* dev_pr
 template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN>
 static int launch_conv_p(const ConvArgs& a0, hipStream_t st) {
     ConvArgs a = a0;
-    a.tiles_m = cdiv(a.M, BM);
-    a.tiles_n = cdiv(a.NOUT, BN);
+    plan_tiles(a, BM, BN);
     const size_t smem = conv_smem_bytes(BM, BN, a.KTOT);
     if (smem > 160 * 1024) {
         set_error("conv: K=%d needs %zu B of LDS (>160 KiB)", a.KTOT, smem);
@@ -422,7 +514,7 @@ static int launch_conv_p(const ConvArgs& a0, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), smem, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.total_tiles), dim3(256), smem, st, a);
     return check_launch("conv_igemm");
 }
 
@@ -693,6 +785,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_grouped_kernel(const WgradArgs
         const int mid = (lo + hi) >> 1;
         if (prefix[mid] <= bid) lo = mid; else hi = mid;
     }
+    lo = __builtin_amdgcn_readfirstlane(lo);           // wave-uniform: scalar loads of args[lo]
     const WgradArgs a = args[lo];
     const int local = bid - prefix[lo];
     const int gxy = a.gx * a.gy;
@@ -805,6 +898,7 @@ static int make_dgrad_args(const fn_conv_desc* d, ConvArgs& a) {
     a.M = d->N * d->H * d->W; a.PH = d->H; a.PW = d->W; a.SH = d->OH; a.SW = d->OW; a.CS = d->Cout;
     a.NOUT = d->Cin; a.KTOT = d->KH * d->KW * d->Cout; a.KH = d->KH; a.KW = d->KW;
     a.so = 1; a.sk = -1; a.offy = d->pad_h; a.offx = d->pad_w; a.dshift = d->stride == 2 ? 1 : 0;
+    a.s2 = d->stride == 2 ? 1 : 0;
     a.ld_src = d->ld_y; a.ld_out = d->ld_x; a.ld_res = 0;
     a.relu = 0; a.accumulate = d->accumulate; a.out_f32 = d->out_f32; a.scale = 1.f;
     a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0) ? 1 : 0;
@@ -853,10 +947,9 @@ extern "C" int fn_conv2d_group_build(const fn_conv_desc* descs, int n, int op, i
         FN_REQUIRE(descs[i].dtype == descs[0].dtype, "conv_group_build: mixed dtypes");
         if (plain0 < 0) plain0 = a.plain;
         FN_REQUIRE(a.plain == plain0, "conv_group_build: 1x1 and general convolutions cannot share a group");
-        a.tiles_m = cdiv(a.M, bm);
-        a.tiles_n = cdiv(a.NOUT, bn);
+        plan_tiles(a, bm, bn);
         host_prefix[i] = (int32_t)total;
-        total += (long)a.tiles_m * a.tiles_n;
+        total += (long)a.total_tiles;
         const size_t sm = conv_smem_bytes(bm, bn, a.KTOT);
         if (sm > smem) smem = sm;
         out[i] = a;
