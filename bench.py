@@ -186,7 +186,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=90)
     ap.add_argument("--pool", type=int, default=180)
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the dependency scheduler may use (1 = serial)")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the dependency scheduler may use (1 = serial)")
     ap.add_argument("--dump-ops", default=None, help="write per-launch HIP-event timings (eager) to this JSON file")
     args = ap.parse_args()
 

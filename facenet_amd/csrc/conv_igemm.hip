@@ -532,12 +532,13 @@ static void choose_conv_tile(int M, int NOUT, int& bm, int& bn) {
         const long w = (long)cdiv(NOUT, c) * c;
         if (w < best) { best = w; bn = c; }
     }
+    static const int minb = getenv("FN_CONV_MINBLOCKS") ? atoi(getenv("FN_CONV_MINBLOCKS")) : 384;   // tuning aid
     bm = 32;
     for (int c : {128, 64}) {
-        if ((long)cdiv(M, c) * cdiv(NOUT, bn) >= 384) { bm = c; break; }
+        if ((long)cdiv(M, c) * cdiv(NOUT, bn) >= minb) { bm = c; break; }
     }
     // narrow the N tile as well when even 32-row tiles leave most CUs idle
-    while (bm == 32 && bn > 32 && (long)cdiv(M, 32) * cdiv(NOUT, bn) < 384) bn >>= 1;
+    while (bm == 32 && bn > 32 && (long)cdiv(M, 32) * cdiv(NOUT, bn) < minb) bn >>= 1;
 }
 
 // the nine tile variants: BM, BN, waves (M x N), register stages

@@ -139,7 +139,7 @@ def _streams_for(net: Network, n_streams: int) -> StreamSet:
 class Trainer:
     def __init__(self, net: Network, batch: int, loss: str = "triplet", alpha: float = 0.2, lr: float = 0.05, beta1: float = 0.9,
                  beta2: float = 0.999, epsilon: float = 0.1, l2: float = L2_WEIGHT, world_size: int = 1, process_group=None,
-                 n_buckets: int = 6, n_streams: int = 2, group_wgrad: bool = True):
+                 n_buckets: int = 6, n_streams: int = 1, group_wgrad: bool = True):
         self.group_wgrad = group_wgrad
         if loss not in ("triplet", "softmax"):
             raise ValueError(f"unknown loss {loss!r}")
@@ -354,7 +354,7 @@ class TripletMiner:
     """Embeds a PxK pool with the inference path, selects triplets on device and assembles the train batch."""
 
     def __init__(self, net: Network, pool_size: int, labels: Sequence[int], nrof_triplets: int, alpha: float = 0.2, seed: int = 0,
-                 semi_hard: bool = False, n_streams: int = 2, group: bool = True):
+                 semi_hard: bool = False, n_streams: int = 1, group: bool = True):
         self.group = group
         self.net, self.n, self.T, self.alpha, self.seed, self.semi_hard = net, pool_size, nrof_triplets, alpha, seed, semi_hard
         dev = net.device
