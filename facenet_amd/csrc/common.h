@@ -91,6 +91,16 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Bijective XCD-aware remap: blocks b and b+8 share an XCD (and its 4 MiB L2).  Give each XCD a contiguous run of the
+// work-item space; every kernel of the step uses the SAME rows->XCD partition (row fraction x/8 .. (x+1)/8 on XCD x), so
+// what one kernel wrote is still in the L2 of the XCD that reads it in the next kernel (per-XCD L2s are not coherent:
+// anything written on another XCD comes from the memory side).  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace fn

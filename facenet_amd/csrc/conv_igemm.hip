@@ -60,14 +60,6 @@ struct ConvArgs {
     int total_tiles;
 };
 
-// Bijective XCD-aware remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
-// contiguous run of tiles so neighbouring tiles (same A rows / same weights) hit one L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-    return base + (bid >> 3);
-}
-
 // class mode: taps ky in {qy, qy+2, ..}, kx in {qx, qx+2, ..}
 __device__ __forceinline__ int ktab_entry_s2(int kgroup, int CS, int KH, int KW, int qy, int qx) {
     const int nky = (KH - qy + 1) >> 1, nkx = (KW - qx + 1) >> 1;

@@ -109,7 +109,9 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* 
                                                           float* __restrict__ save_shift, float* __restrict__ mm, float* __restrict__ mv,
                                                           float momentum, float eps, int relu, int rows_per_block) {
     __shared__ float s_scale[64], s_shift[64], s_part[4][2][64];
-    const int c0 = blockIdx.y * 64;
+    const int lin_ = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);   // rows -> XCD like the convolutions
+    const int bx_ = lin_ / gridDim.y, by_ = lin_ - bx_ * gridDim.y;
+    const int c0 = by_ * 64;
     {   // replica sums: 4 thread groups x 64 channels, independent loads in flight (a rolled serial loop would expose
         // one memory latency per replica)
         const int cc = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* 
         const float shf = beta[c] - mean * rstd;
         s_scale[threadIdx.x] = rstd;
         s_shift[threadIdx.x] = shf;
-        if (blockIdx.x == 0) {
+        if (bx_ == 0) {
             save_scale[c] = rstd;
             save_shift[c] = shf;
             if (mm) {
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* 
     float sc[8], sf[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = s_scale[tx * 8 + e]; sf[e] = s_shift[tx * 8 + e]; }
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const int r0 = bx_ * rows_per_block, r1 = min(M, r0 + rows_per_block);
     const int c = c0 + tx * 8;
     for (int r = r0 + ty; r < r1; r += TY) {
         float v[8];
@@ -179,12 +181,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const unsigned 
                                                                  float* __restrict__ s2, int relu, int rows_per_block) {
     // (dbeta, s2) here are the two halves of the accumulator workspace: acc[c] and acc[sq_off + c]
     __shared__ float red[32][2 * 64 + 1];
-    const int c0 = blockIdx.y * 64;
+    const int lin_ = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);   // rows -> XCD like the convolutions
+    const int bx_ = lin_ / gridDim.y, by_ = lin_ - bx_ * gridDim.y;
+    const int c0 = by_ * 64;
     const int ncg = min(8, (C - c0) >> 3);          // 16-B channel groups in this stripe
     const int TX = ncg <= 1 ? 1 : (ncg <= 2 ? 2 : (ncg <= 4 ? 4 : 8));
     const int TY = 256 / TX;                        // 32 .. 256 row lanes
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    const int r0 = blockIdx.x * rows_per_block;
+    const int r0 = bx_ * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
     float a1[8], a2[8];
 #pragma unroll
@@ -240,7 +244,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(unsigned short* 
                                                                 const float* __restrict__ acc, int sq_off, int reps, int rep_stride,
                                                                 int relu, int rows_per_block) {
     __shared__ float s_k1[64], s_k2[64], s_part[4][2][64];
-    const int c0 = blockIdx.y * 64;
+    const int lin_ = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);   // rows -> XCD like the convolutions
+    const int bx_ = lin_ / gridDim.y, by_ = lin_ - bx_ * gridDim.y;
+    const int c0 = by_ * 64;
     {
         const int cc = threadIdx.x & 63, q = threadIdx.x >> 6;
         float s1 = 0.f, s2v = 0.f;
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(unsigned short* 
         const float invM = 1.f / (float)M;
         s_k1[threadIdx.x] = s1 * invM;
         s_k2[threadIdx.x] = s2v * invM;
-        if (blockIdx.x == 0) dbeta[c0 + threadIdx.x] += s1;
+        if (bx_ == 0) dbeta[c0 + threadIdx.x] += s1;
     }
     __syncthreads();
     const int ncg = min(8, (C - c0) >> 3);
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(unsigned short* 
     for (int e = 0; e < 8; ++e) {
         k1[e] = s_k1[tx * 8 + e]; k2[e] = s_k2[tx * 8 + e]; sc[e] = scale[c + e]; sf[e] = shift[c + e]; bt[e] = beta[c + e];
     }
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const int r0 = bx_ * rows_per_block, r1 = min(M, r0 + rows_per_block);
     for (int r = r0 + ty; r < r1; r += TY) {
         unsigned short* p = dz + (long)r * ld_d + c;
         float g[8], yy[8];
@@ -432,10 +438,12 @@ __global__ __launch_bounds__(256) void residual_bwd_kernel(const unsigned short*
                                                            float* __restrict__ dbias, int M, int C, float scale, int relu, int accumulate,
                                                            int rows_per_block) {
     __shared__ float red[32][64 + 1];
-    const int c0 = blockIdx.y * 64;
+    const int lin_ = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);   // rows -> XCD like the convolutions
+    const int bx_ = lin_ / gridDim.y, by_ = lin_ - bx_ * gridDim.y;
+    const int c0 = by_ * 64;
     const int ncg = min(8, (C - c0) >> 3);
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const int r0 = bx_ * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (tx < ncg) {
         for (int r = r0 + ty; r < r1; r += 32) {
