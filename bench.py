@@ -93,7 +93,9 @@ def kernel_roofline(trainer, miner, lib, dump=None):
             descs = op.keep[0]
             opi = 0 if kind == "conv_fwd_grouped" else 1
             tname = "__bf16" if descs[0].dtype == 0 else "_Float16"
-            key = f"conv_igemm_grouped_kernel<{tname},{op.name.split(':')[1].replace('x', ',')}>"
+            d0 = descs[0]
+            plain = int(d0.KH == 1 and d0.KW == 1 and d0.stride == 1 and d0.pad_h == 0 and d0.pad_w == 0)
+            key = f"conv_igemm_grouped_kernel<{tname},{op.name.split(':')[1].replace('x', ',')},1x1={plain}>"
             fl = sum(conv_flops(d, opi) for d in descs)
             g = groups.setdefault(key, dict(ms=0.0, flops=0.0, launches=0, bound="mfma"))
             g["flops"] += fl
@@ -113,10 +115,11 @@ def kernel_roofline(trainer, miner, lib, dump=None):
             opi = {"conv_fwd": 0, "conv_dgrad": 1, "conv_wgrad": 2}[kind]
             v = lib.fn_conv2d_variant(C.byref(d), opi)
             tname = "__bf16" if d.dtype == 0 else "_Float16"
+            plain = int(d.KH == 1 and d.KW == 1 and d.stride == 1 and d.pad_h == 0 and d.pad_w == 0)
             if opi == 2:
                 key = f"conv_wgrad_kernel<{tname},{v // 1000},{v % 1000}>"
             else:
-                key = f"conv_igemm_kernel<{tname},{v // 1000},{v % 1000}>"
+                key = f"conv_igemm_kernel<{tname},{v // 1000},{v % 1000},1x1={plain}>"
             g = groups.setdefault(key, dict(ms=0.0, flops=0.0, launches=0, bound="mfma"))
             g["flops"] += conv_flops(d, opi)
             per_op.append(dict(op=op.name, kernel=key, us=round(ms * 1e3, 2), gflop=round(conv_flops(d, opi) / 1e9, 3),
