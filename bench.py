@@ -64,13 +64,15 @@ def pmc_traffic(kernel_key):
     profiles/r01_pmc_hbm_traffic.json); None when the profile is absent."""
     import re
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    m = re.match(r"(conv_igemm_kernel|conv_igemm_grouped_kernel|conv_wgrad_kernel|conv_wgrad_grouped_kernel)<(__bf16|_Float16),(\d+),(\d+)>", kernel_key)
+    m = re.match(r"(conv_igemm_kernel|conv_igemm_grouped_kernel|conv_wgrad_kernel|conv_wgrad_grouped_kernel)"
+                 r"<(__bf16|_Float16),(\d+),(\d+)(?:,1x1=(\d))?>", kernel_key)
     if not (m and os.path.exists(path)):
         return None
     pat = f"{m.group(1)}I{'DF16b' if m.group(2) == '__bf16' else 'DF16_'}Li{m.group(3)}ELi{m.group(4)}E"
+    tail = f"Lb{m.group(5)}E" if m.group(5) is not None else ""
     n = tot = 0.0
     for name, v in json.load(open(path))["kernels"].items():
-        if pat in name:
+        if pat in name and tail in name:
             n += v["launches"]
             tot += v["launches"] * v["hbm_bytes_per_launch"]
     return round(tot / n) if n else None
