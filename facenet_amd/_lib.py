@@ -70,6 +70,7 @@ _SIGNATURES = {
     "fn_pairwise_sqdist": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "fn_select_triplets": [_p, _p, _i, _f, _i, _u, _i, _p, _p, _p],
     "fn_triplet_loss_fwd_bwd": [_p, _p, _p, _i, _i, _f, _p],
+    "fn_confidence_counts": [_p, _p, _i, _i, _p, _i, _i, _p, _p, _p],
     "fn_softmax_xent_fwd_bwd": [_p, _i, _p, _p, _p, _i, _p, _i, _i, _f, _i, _p],
     "fn_adam_keras": [_p, _p, _p, _p, _p, _l, _l, _l, _p, _f, _f, _f, _f, _i, _p],
     "fn_adam_tick": [_p, _f, _f, _p],

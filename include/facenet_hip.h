@@ -142,6 +142,13 @@ int fn_select_triplets(const float* dist, const int32_t* labels, int n, float al
                        int semi_hard, int32_t* triplets, int32_t* info, void* stream);
 int fn_triplet_loss_fwd_bwd(const float* emb, float* demb, float* loss, int T, int E, float alpha, void* stream);
 
+/* ---- face-to-face validation statistics: facenet/statistics.py:111-138 (ConfidenceMatrix) with the class-balanced
+ * weights of SimilarityCalculator.evaluate (:92-103).  emb fp32 [n,E], unit-norm rows grouped by class (class c = rows
+ * cls_start[c] .. cls_start[c+1]); thresholds ascending, T <= 256; out fp64 [4*T] = tp | tn | fp | fn;
+ * range[2] = ordered-int min/max of the raw dot products (for the reference's +-(1+atol) check, :40-42). */
+int fn_confidence_counts(const float* emb, const int32_t* cls_start, int C, int E, const float* thresholds, int T, int metric,
+                         double* out, int32_t* range, void* stream);
+
 /* ---- softmax classifier loss: apps/train_softmax.py:91 (SparseCategoricalCrossentropy(from_logits)) */
 int fn_softmax_xent_fwd_bwd(const float* logits, int ld, const int32_t* labels, float* loss, void* dlogits_lp, int ld_d, float* dbias, int N,
                             int C, float grad_scale, int dtype, void* stream);
