@@ -83,6 +83,33 @@ __global__ __launch_bounds__(256) void img_apply_kernel(const SRC* __restrict__ 
     }
 }
 
+// tf.image.resize(images, [size, size]) as called at facenet/facenet.py:70: bilinear, half-pixel centres, no antialias
+// (TF2 defaults): src = (dst + 0.5) * in/out - 0.5, lower = max(floor(src), 0), upper = min(ceil(src), in-1).
+template <typename SRC>
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const SRC* __restrict__ img, float* __restrict__ out, int N, int H, int W,
+                                                              int OH, int OW) {
+    const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
+    const long total = (long)N * OH * OW;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int ox = (int)(t % OW);
+        const int oy = (int)((t / OW) % OH);
+        const int n = (int)(t / ((long)OW * OH));
+        const float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+        const float fy0 = floorf(fy), fx0 = floorf(fx);
+        const int y0 = max((int)fy0, 0), y1 = min((int)ceilf(fy), H - 1);
+        const int x0 = max((int)fx0, 0), x1 = min((int)ceilf(fx), W - 1);
+        const float ly = fy - fy0, lx = fx - fx0;
+        const SRC* p = img + (long)n * H * W * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v00 = (float)p[((long)y0 * W + x0) * 3 + c], v01 = (float)p[((long)y0 * W + x1) * 3 + c];
+            const float v10 = (float)p[((long)y1 * W + x0) * 3 + c], v11 = (float)p[((long)y1 * W + x1) * 3 + c];
+            const float top = v00 + (v01 - v00) * lx, bot = v10 + (v11 - v10) * lx;
+            out[t * 3 + c] = top + (bot - top) * ly;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_images_kernel(const uint8_t* __restrict__ pool, const int32_t* __restrict__ idx,
                                                             uint8_t* __restrict__ out, int bytes) {
     const int i = blockIdx.y;
@@ -610,6 +637,14 @@ extern "C" int fn_image_normalize(const uint8_t* img, void* out, float* work, in
 }
 extern "C" int fn_image_normalize_f32(const float* img, void* out, float* work, int N, int HW, int mode, int dtype, void* stream) {
     return image_normalize_impl<float>(img, out, work, N, HW, mode, dtype, stream);
+}
+
+extern "C" int fn_image_resize_bilinear(const void* img, int src_is_f32, float* out, int N, int H, int W, int OH, int OW, void* stream) {
+    FN_REQUIRE(img && out && N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "image_resize: bad arguments");
+    const int grid = grid_for((long)N * OH * OW);
+    if (src_is_f32) hipLaunchKernelGGL(resize_bilinear_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)img, out, N, H, W, OH, OW);
+    else hipLaunchKernelGGL(resize_bilinear_kernel<uint8_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)img, out, N, H, W, OH, OW);
+    return check_launch("image_resize");
 }
 
 extern "C" int fn_gather_images(const uint8_t* pool, const int32_t* idx, uint8_t* out, int n_out, int bytes, void* stream) {

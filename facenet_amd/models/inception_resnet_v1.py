@@ -50,9 +50,14 @@ class InceptionResnetV1:
         x = torch.as_tensor(np.asarray(inputs)) if not torch.is_tensor(inputs) else inputs
         if x.dim() != 4 or x.shape[3] != 3:
             raise ValueError(f"expected NHWC images [N,{net.image_size},{net.image_size},3], got {tuple(x.shape)}")
-        if x.shape[1] != net.image_size or x.shape[2] != net.image_size:
-            raise ValueError("tf.image.resize (facenet.py:70) is the identity at the configured size; other sizes are not supported")
         n = x.shape[0]
+        if x.shape[1] != net.image_size or x.shape[2] != net.image_size:     # tf.image.resize, facenet.py:70
+            src = x.to(net.device).contiguous()
+            if src.dtype not in (torch.uint8, torch.float32):
+                src = src.to(torch.float32)
+            x = torch.empty(n, net.image_size, net.image_size, 3, dtype=torch.float32, device=net.device)
+            _lib.check(net.lib.fn_image_resize_bilinear(_ptr(src), 1 if src.dtype == torch.float32 else 0, _ptr(x), n, src.shape[1], src.shape[2],
+                                                        net.image_size, net.image_size, net.stream()), "image_resize")
         plan = self._plan(n, training)
         st = net.stream()
         if not training:

@@ -90,6 +90,9 @@ int fn_conv2d_variant(const fn_conv_desc* d, int op);
  * min/max to [-1,1], mode 1 = per_image_standardization.  `work` = fp32 [4*N] scratch. */
 int fn_image_normalize(const uint8_t* img, void* out, float* work, int N, int HW, int mode, int dtype, void* stream);
 int fn_image_normalize_f32(const float* img, void* out, float* work, int N, int HW, int mode, int dtype, void* stream);
+/* tf.image.resize(images, [size,size]) of facenet.py:70 (bilinear, half-pixel centres, no antialias): u8 or fp32 NHWC
+ * [N,H,W,3] -> fp32 [N,OH,OW,3]; the identity at the configured size, so plans skip it then. */
+int fn_image_resize_bilinear(const void* img, int src_is_f32, float* out, int N, int H, int W, int OH, int OW, void* stream);
 /* gather rows of a u8 image pool by index (triplet batch assembly): out[i] = pool[idx[i]] */
 int fn_gather_images(const uint8_t* pool, const int32_t* idx, uint8_t* out, int n_out, int bytes_per_image, void* stream);
 
