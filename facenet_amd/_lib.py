@@ -58,8 +58,8 @@ _SIGNATURES = {
     "fn_gather_images": [_p, _p, _p, _i, _i, _p],
     "fn_bn_relu_train_fwd": [_p, _i, _p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p],
     "fn_bn_relu_train_bwd": [_p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    "fn_maxpool3x3s2_fwd": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
-    "fn_maxpool3x3s2_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "fn_maxpool3x3s2_fwd": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p],
+    "fn_maxpool3x3s2_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p],
     "fn_avgpool_fwd": [_p, _p, _i, _i, _i, _i, _p],
     "fn_avgpool_bwd": [_p, _p, _i, _i, _i, _i, _p],
     "fn_residual_bwd": [_p, _p, _p, _p, _p, _i, _i, _f, _i, _i, _i, _p],

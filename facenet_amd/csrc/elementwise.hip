@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(unsigned short* 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* __restrict__ x, int ld_x, unsigned short* __restrict__ y,
-                                                          int ld_y, int N, int H, int W, int C, int OH, int OW) {
+                                                          int ld_y, int N, int H, int W, int C, int OH, int OW, uint8_t* __restrict__ amax) {
     const int CG = C >> 3;
     const long total = (long)N * OH * OW * CG;
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
@@ -339,8 +339,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* 
         const int oy = (int)(pix % OH);
         const int n = (int)(pix / OH);
         float m[8];
+        unsigned am[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = -3.0e38f;
+        for (int e = 0; e < 8; ++e) { m[e] = -3.0e38f; am[e] = 0; }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -348,9 +349,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* 
                 float v[8];
                 unpack8<T>(*reinterpret_cast<const u32x4*>(x + ((long)(n * H + oy * 2 + ky) * W + ox * 2 + kx) * ld_x + cg * 8), v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+                for (int e = 0; e < 8; ++e)
+                    if (v[e] > m[e]) { m[e] = v[e]; am[e] = ky * 3 + kx; }   // strict >: the FIRST maximum wins (tf / torch CPU tie rule)
             }
         *reinterpret_cast<u32x4*>(y + ((long)(n * OH + oy) * OW + ox) * ld_y + cg * 8) = pack8<T>(m);
+        if (amax) {
+            const unsigned lo = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24), hi = am[4] | (am[5] << 8) | (am[6] << 16) | (am[7] << 24);
+            *reinterpret_cast<uint2*>(amax + ((long)(n * OH + oy) * OW + ox) * C + cg * 8) = make_uint2(lo, hi);
+        }
     }
 }
 
@@ -419,6 +425,46 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned short* 
 }
 
 // AvgPool2D over the whole HW map (3x3 -> 1x1 at 160x160, :460) + Flatten
+// argmax form: 4 x (8 B argmax + 16 B dy) per thread instead of re-deriving the maximum from up to 36 window loads
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_amax_kernel(const uint8_t* __restrict__ amax, const unsigned short* __restrict__ dy, int ld_dy,
+                                                               unsigned short* __restrict__ dx, int ld_dx, int N, int H, int W, int C, int OH,
+                                                               int OW, int accumulate) {
+    const int CG = C >> 3;
+    const long total = (long)N * H * W * CG;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int cg = (int)(t % CG);
+        long pix = t / CG;
+        const int ix = (int)(pix % W); pix /= W;
+        const int iy = (int)(pix % H);
+        const int n = (int)(pix / H);
+        float g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int oy_lo = max(0, (iy - 1) >> 1), oy_hi = min(OH - 1, iy >> 1);
+        const int ox_lo = max(0, (ix - 1) >> 1), ox_hi = min(OW - 1, ix >> 1);
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const unsigned my = (iy - 2 * oy) * 3 + (ix - 2 * ox);
+                const long o = (long)(n * OH + oy) * OW + ox;
+                const uint2 a = *reinterpret_cast<const uint2*>(amax + o * C + cg * 8);
+                float d[8];
+                unpack8<T>(*reinterpret_cast<const u32x4*>(dy + o * ld_dy + cg * 8), d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned am = ((e < 4 ? a.x : a.y) >> (8 * (e & 3))) & 0xffu;
+                    g[e] += (am == my) ? d[e] : 0.f;
+                }
+            }
+        unsigned short* op = dx + ((long)(n * H + iy) * W + ix) * ld_dx + cg * 8;
+        if (accumulate) {
+            float pv[8];
+            unpack8<T>(*reinterpret_cast<const u32x4*>(op), pv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] += pv[e];
+        }
+        *reinterpret_cast<u32x4*>(op) = pack8<T>(g);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int N, int HW,
                                                           int C) {
@@ -518,9 +564,11 @@ __global__ __launch_bounds__(64) void head_bn_fwd_kernel(const float* __restrict
     float mean, var;
     if (training) {
         float s = 0.f;
+#pragma unroll 8
         for (int n = 0; n < N; ++n) s += y[(long)n * E + c];
         mean = s / (float)N;
         float q = 0.f;
+#pragma unroll 8
         for (int n = 0; n < N; ++n) { const float d = y[(long)n * E + c] - mean; q += d * d; }
         var = q / (float)N;
         mm[c] = mm[c] * momentum + mean * (1.f - momentum);
@@ -532,6 +580,7 @@ __global__ __launch_bounds__(64) void head_bn_fwd_kernel(const float* __restrict
     const float rstd = rsqrtf(var + eps);
     if (save_mean) { save_mean[c] = mean; save_rstd[c] = rstd; }
     const float b = beta[c];
+#pragma unroll 8
     for (int n = 0; n < N; ++n) out[(long)n * E + c] = (y[(long)n * E + c] - mean) * rstd + b;
 }
 
@@ -543,6 +592,7 @@ __global__ __launch_bounds__(64) void head_bn_bwd_kernel(const float* __restrict
     if (c >= E) return;
     const float mean = save_mean[c], rstd = save_rstd[c];
     float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
     for (int n = 0; n < N; ++n) {
         const float g = dout[(long)n * E + c];
         s1 += g;
@@ -550,6 +600,7 @@ __global__ __launch_bounds__(64) void head_bn_bwd_kernel(const float* __restrict
     }
     dbeta[c] += s1;
     const float k1 = s1 / (float)N, k2 = s2 / (float)N;
+#pragma unroll 8
     for (int n = 0; n < N; ++n) {
         const float xh = (y[(long)n * E + c] - mean) * rstd;
         dy[(long)n * E + c] = LP<T>::from_f32(rstd * (dout[(long)n * E + c] - k1 - xh * k2));
@@ -687,18 +738,25 @@ extern "C" int fn_bn_relu_train_bwd(void* dz, int ld_d, const void* y, int ld_y,
     return check_launch("bn_relu_bwd");
 }
 
-extern "C" int fn_maxpool3x3s2_fwd(const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, int dtype, void* stream) {
+extern "C" int fn_maxpool3x3s2_fwd(const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, uint8_t* argmax, int dtype,
+                                   void* stream) {
     DT_CHECK(dtype);
     FN_REQUIRE(x && y && N > 0 && H >= 3 && W >= 3 && C % 8 == 0 && ld_x % 8 == 0 && ld_y % 8 == 0, "maxpool_fwd: bad arguments");
     const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
     const int grid = grid_for((long)N * OH * OW * (C / 8));
-    LAUNCH_T(dtype, maxpool_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, ld_x, (unsigned short*)y, ld_y, N, H, W, C, OH, OW);
+    LAUNCH_T(dtype, maxpool_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, ld_x, (unsigned short*)y, ld_y, N, H, W, C, OH, OW, argmax);
     return check_launch("maxpool_fwd");
 }
 
 extern "C" int fn_maxpool3x3s2_bwd(const void* x, int ld_x, const void* dy, int ld_dy, void* dx, int ld_dx, int N, int H, int W, int C,
-                                   int accumulate, int dtype, void* stream) {
+                                   const uint8_t* argmax, int accumulate, int dtype, void* stream) {
     DT_CHECK(dtype);
+    if (argmax) {
+        FN_REQUIRE(dy && dx && N > 0 && H >= 3 && W >= 3 && C % 8 == 0 && ld_dy % 8 == 0 && ld_dx % 8 == 0, "maxpool_bwd: bad arguments");
+        const int OH2 = (H - 3) / 2 + 1, OW2 = (W - 3) / 2 + 1;
+        LAUNCH_T(dtype, maxpool_bwd_amax_kernel, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, argmax, (const unsigned short*)dy, ld_dy, (unsigned short*)dx, ld_dx, N, H, W, C, OH2, OW2, accumulate);
+        return check_launch("maxpool_bwd");
+    }
     FN_REQUIRE(x && dy && dx && N > 0 && H >= 3 && W >= 3 && C % 8 == 0 && ld_x % 8 == 0 && ld_dy % 8 == 0 && ld_dx % 8 == 0,
                "maxpool_bwd: bad arguments");
     const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;

@@ -644,8 +644,13 @@ class Lowering:
 
     def _fwd_maxpool(self, r: Rec):
         x, y = r.x, r.y
+        am = None
+        if self.training and x.buf.name != "input":   # 1-byte argmax map for the backward (first maximum of every window)
+            am = torch.zeros(self.N, y.buf.H, y.buf.W, x.C, dtype=torch.uint8, device=self.net.device)
+            r.extra["argmax"] = am
         self._emit(self.fwd, "maxpool_fwd", self.net.lib.fn_maxpool3x3s2_fwd, _ptr(x.buf.act, x.c0), x.buf.C, _ptr(y.buf.act, y.c0), y.buf.C,
-                   self.N, x.buf.H, x.buf.W, x.C, self.dt, r=[self._ra(x)], w=[self._ra(y)])
+                   self.N, x.buf.H, x.buf.W, x.C, _ptr(am) if am is not None else None, self.dt,
+                   r=[self._ra(x)], w=[self._ra(y)] + ([region(am)] if am is not None else []))
 
     def _fwd_avgpool(self, r: Rec):
         x, y = r.x, r.y
@@ -754,9 +759,10 @@ class Lowering:
         if x.buf.name == "input":
             return
         acc = self._grad_mode(x)
+        am = r.extra.get("argmax")
         self._emit(self.bwd, "maxpool_bwd", self.net.lib.fn_maxpool3x3s2_bwd, _ptr(x.buf.act, x.c0), x.buf.C, _ptr(y.buf.grad, y.c0), y.buf.C,
-                   _ptr(x.buf.grad, x.c0), x.buf.C, self.N, x.buf.H, x.buf.W, x.C, acc, self.dt,
-                   r=[self._ra(x), self._rg(y)], w=[self._rg(x)])
+                   _ptr(x.buf.grad, x.c0), x.buf.C, self.N, x.buf.H, x.buf.W, x.C, _ptr(am) if am is not None else None, acc, self.dt,
+                   r=[self._ra(x), self._rg(y)] + ([region(am)] if am is not None else []), w=[self._rg(x)])
 
     def _bwd_avgpool(self, r: Rec):
         x, y = r.x, r.y

@@ -115,9 +115,11 @@ int fn_bn_relu_train_bwd(void* dz, int ld_d, const void* y, int ld_y, int M, int
                          int reduced, int relu, int dtype, void* stream);
 
 /* ---- pooling: MaxPool2D(3, strides=2, 'valid') :301,369,409 ; AvgPool2D([3,3]) + Flatten :460-461 */
-int fn_maxpool3x3s2_fwd(const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, int dtype, void* stream);
+/* argmax (optional, u8 [N,OH,OW,C]): scan position 0..8 of the FIRST maximum of every window; when given to the backward it
+ * replaces the recomputation from x (x may then be NULL). */
+int fn_maxpool3x3s2_fwd(const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, uint8_t* argmax, int dtype, void* stream);
 int fn_maxpool3x3s2_bwd(const void* x, int ld_x, const void* dy, int ld_dy, void* dx, int ld_dx, int N, int H, int W, int C,
-                        int accumulate, int dtype, void* stream);
+                        const uint8_t* argmax, int accumulate, int dtype, void* stream);
 int fn_avgpool_fwd(const void* x, void* y, int N, int HW, int C, int dtype, void* stream);
 int fn_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype, void* stream);
 

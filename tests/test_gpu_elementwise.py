@@ -81,17 +81,22 @@ def test_maxpool_fwd_bwd(lib, dt):
     x = xb[..., 8:8 + Cc]
     OH = OW = 8
     yb = torch.zeros(N, OH, OW, 48, dtype=lp_dtype(dt), device="cuda")
-    _lib.check(lib.fn_maxpool3x3s2_fwd(ptr(xb, 8), 64, ptr(yb, 8), 48, N, H, W, Cc, dt, stream()))
+    amax = torch.zeros(N, OH, OW, Cc, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.fn_maxpool3x3s2_fwd(ptr(xb, 8), 64, ptr(yb, 8), 48, N, H, W, Cc, ptr(amax), dt, stream()))
     xr = x.float().cpu().permute(0, 3, 1, 2).clone().requires_grad_(True)
     yr = F.max_pool2d(xr, 3, 2)
     assert torch.equal(yb[..., 8:8 + Cc].float().cpu(), yr.detach().permute(0, 2, 3, 1))
     dy = _rand((N, OH, OW, 48), dt, seed=6)
     yr.backward(dy[..., 8:8 + Cc].float().cpu().permute(0, 3, 1, 2))
     dx = torch.zeros(N, H, W, 64, dtype=lp_dtype(dt), device="cuda")
-    _lib.check(lib.fn_maxpool3x3s2_bwd(ptr(xb, 8), 64, ptr(dy, 8), 48, ptr(dx, 8), 64, N, H, W, Cc, 0, dt, stream()))
+    _lib.check(lib.fn_maxpool3x3s2_bwd(ptr(xb, 8), 64, ptr(dy, 8), 48, ptr(dx, 8), 64, N, H, W, Cc, None, 0, dt, stream()))
     torch.cuda.synchronize()
     assert rel_err(dx[..., 8:8 + Cc], xr.grad.permute(0, 2, 3, 1)) < (4e-3 if dt == BF else 5e-4)
-    _lib.check(lib.fn_maxpool3x3s2_bwd(ptr(xb, 8), 64, ptr(dy, 8), 48, ptr(dx, 8), 64, N, H, W, Cc, 1, dt, stream()))
+    dx2 = torch.zeros_like(dx)      # argmax form: identical result, no window recomputation
+    _lib.check(lib.fn_maxpool3x3s2_bwd(None, 64, ptr(dy, 8), 48, ptr(dx2, 8), 64, N, H, W, Cc, ptr(amax), 0, dt, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(dx2, dx)
+    _lib.check(lib.fn_maxpool3x3s2_bwd(ptr(xb, 8), 64, ptr(dy, 8), 48, ptr(dx, 8), 64, N, H, W, Cc, None, 1, dt, stream()))
     torch.cuda.synchronize()
     assert rel_err(dx[..., 8:8 + Cc], 2 * xr.grad.permute(0, 2, 3, 1)) < 1e-2
 
