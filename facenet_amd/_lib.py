@@ -55,6 +55,7 @@ _SIGNATURES = {
     "fn_image_normalize": [_p, _p, _p, _i, _i, _i, _i, _p],
     "fn_image_normalize_f32": [_p, _p, _p, _i, _i, _i, _i, _p],
     "fn_image_resize_bilinear": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
+    "fn_crop_or_pad_u8": [_p, _p, _p, _p, _i, _i, _p],
     "fn_gather_images": [_p, _p, _p, _i, _i, _p],
     "fn_bn_relu_train_fwd": [_p, _i, _p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p],
     "fn_bn_relu_train_bwd": [_p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

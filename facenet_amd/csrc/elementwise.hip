@@ -698,6 +698,37 @@ extern "C" int fn_image_resize_bilinear(const void* img, int src_is_f32, float* 
     return check_launch("image_resize");
 }
 
+// tf.image.resize_with_crop_or_pad (ImageLoader, facenet.py:45-54): a ragged batch of decoded HWC u8 images, packed back to
+// back in `src` (image n starts at byte off[n], is hw[2n] x hw[2n+1] x 3), centre-cropped / zero-padded to S x S.
+// One thread per 4 output bytes (one 32-bit store); source rows are unaligned byte runs, read through L1.
+__global__ __launch_bounds__(256) void crop_or_pad_kernel(const uint8_t* __restrict__ src, const long long* __restrict__ off,
+                                                          const int* __restrict__ hw, uint8_t* __restrict__ dst, int S) {
+    const int n = blockIdx.y;
+    const int h = hw[2 * n], w = hw[2 * n + 1];
+    const int cy = max((h - S) / 2, 0), cx = max((w - S) / 2, 0);     // offset_crop = max(-diff // 2, 0)
+    const int py = max((S - h) / 2, 0), px = max((S - w) / 2, 0);     // offset_pad  = max( diff // 2, 0)
+    const int ch = min(h, S), cw = min(w, S);
+    const uint8_t* im = src + off[n];
+    const int words = S * S * 3 / 4;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < words; t += gridDim.x * 256) {
+        unsigned v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int e = t * 4 + b;
+            const int c = e % 3, pix = e / 3;
+            const int x = pix % S - px, y = pix / S - py;
+            if (x >= 0 && x < cw && y >= 0 && y < ch) v |= (unsigned)im[((long)(y + cy) * w + (x + cx)) * 3 + c] << (8 * b);
+        }
+        reinterpret_cast<unsigned*>(dst + (long)n * S * S * 3)[t] = v;
+    }
+}
+
+extern "C" int fn_crop_or_pad_u8(const uint8_t* src, const long long* offsets, const int32_t* hw, uint8_t* dst, int N, int S, void* stream) {
+    FN_REQUIRE(src && offsets && hw && dst && N > 0 && S > 0 && (S * S * 3) % 4 == 0, "crop_or_pad: bad arguments");
+    hipLaunchKernelGGL(crop_or_pad_kernel, dim3(cdiv(S * S * 3 / 4, 256 * 4), N), dim3(256), 0, (hipStream_t)stream, src, offsets, hw, dst, S);
+    return check_launch("crop_or_pad");
+}
+
 extern "C" int fn_gather_images(const uint8_t* pool, const int32_t* idx, uint8_t* out, int n_out, int bytes, void* stream) {
     FN_REQUIRE(pool && idx && out && n_out > 0 && bytes > 0 && bytes % 16 == 0, "gather_images: bad arguments");
     hipLaunchKernelGGL(gather_images_kernel, dim3(8, n_out), dim3(256), 0, (hipStream_t)stream, pool, idx, out, bytes);

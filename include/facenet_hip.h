@@ -93,6 +93,11 @@ int fn_image_normalize_f32(const float* img, void* out, float* work, int N, int 
 /* tf.image.resize(images, [size,size]) of facenet.py:70 (bilinear, half-pixel centres, no antialias): u8 or fp32 NHWC
  * [N,H,W,3] -> fp32 [N,OH,OW,3]; the identity at the configured size, so plans skip it then. */
 int fn_image_resize_bilinear(const void* img, int src_is_f32, float* out, int N, int H, int W, int OH, int OW, void* stream);
+/* tf.image.resize_with_crop_or_pad(image, size, size) of ImageLoader.__call__ (facenet.py:45-54) for a ragged batch of decoded
+ * HWC u8 images packed back to back: image n starts at byte offsets[n] of src and is hw[2n] x hw[2n+1] x 3; centre crop
+ * (offset max((h-S)//2, 0)) and centre zero-pad (offset max((S-h)//2, 0)) to dst u8 [N,S,S,3].  Sizes are not checked against
+ * the src allocation: the caller owns the packing. */
+int fn_crop_or_pad_u8(const uint8_t* src, const long long* offsets, const int32_t* hw, uint8_t* dst, int N, int S, void* stream);
 /* gather rows of a u8 image pool by index (triplet batch assembly): out[i] = pool[idx[i]] */
 int fn_gather_images(const uint8_t* pool, const int32_t* idx, uint8_t* out, int n_out, int bytes_per_image, void* stream);
 

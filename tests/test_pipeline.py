@@ -1,0 +1,175 @@
+"""Input pipeline: host logic and the oracle on CPU, the crop/pad kernel and the prefetching
+iterator on the GPU.  Parity unpinned (see oracle/pipeline_oracle.py): the expected values are the published
+tf.image.resize_with_crop_or_pad algorithm and the reference's generator logic, not reference outputs."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from facenet_amd import dataset
+from facenet_amd.config import Config
+from oracle import pipeline_oracle as po
+
+SIZES = [(160, 160), (250, 250), (161, 159), (100, 300), (300, 100), (1, 1), (159, 160), (165, 155), (480, 640), (2, 513)]
+
+
+def _write_db(root, classes=6, per_class=(7, 5, 9, 6, 5, 8), seed=0):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    truth = {}
+    for c in range(classes):
+        d = root / f"id_{c:03d}"
+        d.mkdir()
+        for i in range(per_class[c]):
+            h, w = SIZES[(c * 3 + i) % len(SIZES)]
+            arr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            f = d / f"img_{i:03d}.png"
+            Image.fromarray(arr).save(f)
+            truth[str(f)] = arr
+    (root / "empty_class").mkdir()
+    (root / "stray_file.txt").write_text("not a class")
+    return truth
+
+
+def test_oracle_crop_or_pad_cases():
+    img = np.arange(5 * 7 * 3, dtype=np.uint8).reshape(5, 7, 3)
+    assert np.array_equal(po.resize_with_crop_or_pad(img, 5, 7), img)
+    c = po.resize_with_crop_or_pad(img, 3, 4)                      # crop offsets (5-3)//2 = 1, (7-4)//2 = 1
+    assert np.array_equal(c, img[1:4, 1:5])
+    p = po.resize_with_crop_or_pad(img, 8, 10)                     # pad offsets (8-5)//2 = 1, (10-7)//2 = 1
+    assert np.array_equal(p[1:6, 1:8], img) and p.sum() == img.sum()
+    m = po.resize_with_crop_or_pad(img, 9, 2)                      # pad rows, crop columns
+    assert np.array_equal(m[2:7], img[:, 2:4]) and not m[:2].any() and not m[7:].any()
+
+
+def test_database_listing_and_errors(tmp_path):
+    truth = _write_db(tmp_path)
+    db = dataset.Database(Config({"path": str(tmp_path)}))
+    assert db.nrof_classes == 6 and db.nrof_images == 40                      # the empty class is dropped
+    assert db.nrof_images_per_class == [7, 5, 9, 6, 5, 8]
+    assert (db.min_nrof_images, db.max_nrof_images) == (5, 9)
+    assert sorted(db.files) == sorted(truth) and db.files == [f for c in db.classes for f in c.files]
+    assert np.array_equal(db.labels, np.repeat(np.arange(6), [7, 5, 9, 6, 5, 8]))
+    assert db.classes[2].nrof_pairs == 36 and repr(db.classes[0]) == "ImageClass (id_000/7)"
+    assert "Number of classes 6" in repr(db)
+    small = dataset.Database(Config({"path": str(tmp_path), "max_nrof_images": 5, "nrof_classes": 3}))
+    assert small.nrof_classes <= 3 and small.max_nrof_images <= 5
+    with pytest.raises(ValueError):
+        dataset.Database(Config({}))
+    with pytest.raises(ValueError):
+        dataset.Database(Config({"path": str(tmp_path / "missing")}))
+    with pytest.raises(ValueError):
+        dataset.ImageClass(Config({"path": str(tmp_path / "missing")}))
+
+
+def test_batch_plans_match_the_oracle(tmp_path):
+    _write_db(tmp_path, per_class=(7, 5, 9, 6, 5, 8))
+    db = dataset.Database(Config({"path": str(tmp_path)}))
+    loader = dataset.ImageLoader(Config({"size": 160}))
+    # sequential batches: file order, short last batch, finite cardinality
+    pipe = db.tf_dataset_api(loader, batch_size=16)
+    plans = list(pipe._plan())
+    assert pipe.cardinality() == 3 and [len(p[0]) for p in plans] == [16, 16, 8]
+    assert [f for p in plans for f in p[0]] == db.files and [l for p in plans for l in p[1]] == db.labels.tolist()
+    # shuffled: every epoch a permutation with labels still attached to their files
+    label_of = dict(zip(db.files, db.labels.tolist()))
+    sh = list(db.tf_dataset_api(loader, batch_size=16, buffer_size=10)._plan())
+    assert sorted(f for p in sh for f in p[0]) == sorted(db.files)
+    assert all(label_of[f] == l for p in sh for f, l in zip(*p))
+    assert db.tf_dataset_api(loader, batch_size=16, repeat=True).cardinality() is None
+    # P x K sampler: fewer than 20 classes raises like random.sample does in the reference's generator
+    cfg = Config({})
+    with pytest.raises(ValueError):
+        next(iter(dataset.pipeline_with_equal_batches(loader, db.classes, cfg)._plan()))
+    assert (cfg.nrof_classes_per_batch, cfg.nrof_examples_per_class) == (20, 5)
+
+
+def test_equal_batches_draws_match_the_oracle():
+    class C:
+        def __init__(self, i, n):
+            self.files = [f"c{i}/f{j}" for j in range(n)]
+    classes = [C(i, 5 + i % 4) for i in range(31)]
+    loader = dataset.ImageLoader(Config({"size": 160}))
+    cfg = Config({})
+    random.seed(1234)
+    plan = iter(dataset.pipeline_with_equal_batches(loader, classes, cfg)._plan())
+    rng = random.Random(1234)
+    for _ in range(5):
+        files, idx = next(plan)
+        ofiles, oidx = po.equal_batches([c.files for c in classes], 20, 5, rng)
+        assert files == ofiles and idx == oidx
+        assert len(files) == 100 and len(set(idx)) == 20 and all(idx.count(i) == 5 for i in set(idx))
+        assert all(f.startswith(f"c{i}/") for f, i in zip(files, idx)) and len(set(files)) == 100
+    assert [c.index for c in classes] == list(range(31))
+
+
+def test_loader_rejects_bad_size():
+    with pytest.raises(ValueError):
+        dataset.ImageLoader(Config({"size": 0}))
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_crop_or_pad_kernel_is_bit_exact():
+    rng = np.random.default_rng(3)
+    arrays = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in SIZES]
+    for size in (160, 96, 182):
+        out = dataset.crop_or_pad_batch(arrays, size)
+        torch.cuda.synchronize()
+        want = np.stack([po.resize_with_crop_or_pad(a, size, size) for a in arrays])
+        assert np.array_equal(out.cpu().numpy(), want)
+    assert dataset.crop_or_pad_batch([], 160).shape == (0, 160, 160, 3)
+    with pytest.raises(ValueError):
+        dataset.crop_or_pad_batch([np.zeros((4, 4), np.uint8)], 160)
+
+
+@pytest.mark.gpu
+def test_pipeline_end_to_end(tmp_path):
+    truth = _write_db(tmp_path)
+    db = dataset.Database(Config({"path": str(tmp_path)}))
+    loader = dataset.ImageLoader(Config({"size": 160}))
+    one = loader(db.files[3])
+    assert one.shape == (160, 160, 3) and np.array_equal(one.cpu().numpy(), po.resize_with_crop_or_pad(truth[db.files[3]], 160, 160))
+    seen = []
+    procs = db.tf_dataset_api(loader, batch_size=16, workers=2, processes=True)     # spawned decode workers: same batches
+    first = next(iter(procs))
+    procs.close()
+    assert np.array_equal(first[0].cpu().numpy(), np.stack([po.resize_with_crop_or_pad(truth[f], 160, 160) for f in db.files[:16]]))
+    for images, labels in db.tf_dataset_api(loader, batch_size=16, workers=4):
+        assert images.dtype == torch.uint8 and images.is_cuda and labels.dtype == torch.int64
+        seen.append((images.cpu().numpy(), labels.cpu().numpy()))
+    assert [len(s[1]) for s in seen] == [16, 16, 8]
+    got = np.concatenate([s[0] for s in seen])
+    want = np.stack([po.resize_with_crop_or_pad(truth[f], 160, 160) for f in db.files])
+    assert np.array_equal(got, want) and np.array_equal(np.concatenate([s[1] for s in seen]), db.labels)
+    # two epochs of a repeating shuffled pipeline, then stop: labels stay attached to their pixels
+    pipe = db.tf_dataset_api(loader, batch_size=10, buffer_size=4, repeat=True, workers=4)
+    index = {f: i for i, f in enumerate(db.files)}
+    n = 0
+    for images, labels in pipe:
+        im, lb = images.cpu().numpy(), labels.cpu().numpy()
+        for k in range(len(lb)):
+            cands = [i for i in np.nonzero(db.labels == lb[k])[0] if np.array_equal(want[i], im[k])]
+            assert cands, "batch image does not belong to its label's class"
+        n += 1
+        if n == 8:
+            break
+
+
+@pytest.mark.gpu
+def test_equal_batches_feed_the_model(tmp_path):
+    per = (5,) * 20
+    _write_db(tmp_path, classes=20, per_class=per)
+    db = dataset.Database(Config({"path": str(tmp_path)}))
+    loader = dataset.ImageLoader(Config({"size": 160}))
+    pipe = dataset.pipeline_with_equal_batches(loader, db.classes, Config({}), workers=4)
+    images, labels = next(iter(pipe))
+    assert images.shape == (100, 160, 160, 3) and sorted(labels.cpu().tolist()) == sorted(list(range(20)) * 5)
+    from facenet_amd import facenet
+    from facenet_amd.models.inception_resnet_v1 import InceptionResnetV1
+    cfg = Config({"size": 160, "normalization": 0})
+    model = InceptionResnetV1(input_shape=facenet.inputs(cfg), image_processing=facenet.ImageProcessing(cfg))
+    emb = model(images[:8])
+    assert emb.shape[0] == 8 and torch.allclose(emb.norm(dim=1), torch.ones(8, device=emb.device), atol=1e-3)
