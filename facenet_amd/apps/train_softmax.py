@@ -6,9 +6,9 @@ model = InceptionResnetV1; network = Sequential([model, Dense(nrof_classes)]) (:
 SparseCategoricalCrossentropy(from_logits=True) (:91); Adam(epsilon=0.1) (:92); LR set per epoch by
 LearningRateScheduler (:80-83); ``train.epoch.size`` steps per epoch (:95-104).
 
-The dataset pipeline (facenet/dataset.py, tf.data) is outside this build's scope: batches
-come from ``batches`` (an iterable of (uint8 images [N,160,160,3], int labels [N])) or, by default, from a seeded
-synthetic generator."""
+Batches come from ``batches`` (an iterable of (uint8 images [N,160,160,3], int labels [N])); ``main`` builds them from
+``cfg.dataset.path`` with facenet_amd.dataset (Database + tf_dataset_api, :28-47 of the reference app) or, when no data
+set is configured, from a seeded synthetic generator."""
 from __future__ import annotations
 
 import time
@@ -67,7 +67,14 @@ def train_softmax(cfg, nrof_classes: int, batches=None, embedding_size: int = 51
 @click.option("--nrof-classes", default=10575, type=int, help="Number of identities (synthetic data when no dataset is wired in).")
 def main(**options):
     cfg = config_mod.load_config(options["config"])
-    train_softmax(cfg, options["nrof_classes"])
+    if cfg.dataset.path:                                          # apps/train_softmax.py:28-47
+        from facenet_amd import dataset
+        loader = dataset.ImageLoader(config=cfg.image)
+        train_dbase = dataset.Database(cfg.dataset)
+        batches = train_dbase.tf_dataset_api(loader=loader, batch_size=cfg.batch_size, repeat=True, buffer_size=10, processes=True)
+        train_softmax(cfg, train_dbase.nrof_classes, batches)
+    else:
+        train_softmax(cfg, options["nrof_classes"])
 
 
 if __name__ == "__main__":

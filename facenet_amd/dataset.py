@@ -254,20 +254,26 @@ class BatchPipeline:
 def tf_dataset_api(files, labels, loader, batch_size, buffer_size=None, repeat=False, **kw):
     """dataset.py:15-43: zip(files, labels) -> optional shuffle -> optional repeat -> batch -> prefetch.  With a
     `buffer_size` the reference shuffles once globally and then through a buffer_size*batch_size window, reshuffled
-    every iteration; here every epoch is a fresh full permutation (the window's limit case).  The last batch of an epoch
-    may be short (`Dataset.batch` default)."""
+    every iteration; here every epoch is a fresh full permutation (the window's limit case).  `repeat` comes before
+    `batch` as in the reference, so a repeating stream has full batches that span epochs and only a finite one ends short."""
     files, labels = list(files), list(np.asarray(labels).tolist())
     if len(files) != len(labels):
         raise ValueError("files and labels differ in length")
     n = len(files)
 
     def plan():
+        bf, bl = [], []
         while True:
             order = np.random.permutation(n) if buffer_size is not None else np.arange(n)
-            for lo in range(0, n, batch_size):
-                idx = order[lo:lo + batch_size]
-                yield [files[i] for i in idx], [labels[i] for i in idx]
-            if not repeat:
+            for i in order:
+                bf.append(files[i])
+                bl.append(labels[i])
+                if len(bf) == batch_size:
+                    yield bf, bl
+                    bf, bl = [], []
+            if not repeat:                       # repeat() sits before batch(): only a finite stream has a short batch
+                if bf:
+                    yield bf, bl
                 return
 
     card = None if repeat else (n + batch_size - 1) // batch_size

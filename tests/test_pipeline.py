@@ -77,7 +77,11 @@ def test_batch_plans_match_the_oracle(tmp_path):
     sh = list(db.tf_dataset_api(loader, batch_size=16, buffer_size=10)._plan())
     assert sorted(f for p in sh for f in p[0]) == sorted(db.files)
     assert all(label_of[f] == l for p in sh for f, l in zip(*p))
-    assert db.tf_dataset_api(loader, batch_size=16, repeat=True).cardinality() is None
+    rep = db.tf_dataset_api(loader, batch_size=16, repeat=True)
+    assert rep.cardinality() is None
+    it = iter(rep._plan())
+    stream = [next(it) for _ in range(5)]                  # repeat() before batch(): full batches across the epoch boundary
+    assert all(len(p[0]) == 16 for p in stream) and [f for p in stream for f in p[0]] == (db.files * 2)[:80]
     # P x K sampler: fewer than 20 classes raises like random.sample does in the reference's generator
     cfg = Config({})
     with pytest.raises(ValueError):
