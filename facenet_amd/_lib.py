@@ -31,6 +31,9 @@ class ConvDesc(C.Structure):
         ("bias", C.c_void_p), ("stats", C.c_void_p), ("resid", C.c_void_p),
         ("bn_y", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_beta", C.c_void_p), ("bn_acc", C.c_void_p),
         ("ld_bn_y", C.c_int32), ("bn_sq_off", C.c_int32), ("bn_replicas", C.c_int32), ("bn_rep_stride", C.c_int32), ("bn_relu", C.c_int32),
+        ("nrm_stats", C.c_void_p), ("nrm_beta", C.c_void_p),
+        ("nrm_sq_off", C.c_int32), ("nrm_replicas", C.c_int32), ("nrm_rep_stride", C.c_int32), ("nrm_count", C.c_int32),
+        ("nrm_eps", C.c_float),
     ]
 
 
@@ -55,6 +58,7 @@ _SIGNATURES = {
     "fn_image_normalize": [_p, _p, _p, _i, _i, _i, _i, _p],
     "fn_image_normalize_f32": [_p, _p, _p, _i, _i, _i, _i, _p],
     "fn_image_resize_bilinear": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
+    "fn_bn_finalize": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p],
     "fn_crop_or_pad_u8": [_p, _p, _p, _p, _i, _i, _p],
     "fn_gather_images": [_p, _p, _p, _i, _i, _p],
     "fn_bn_relu_train_fwd": [_p, _i, _p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p],

@@ -91,6 +91,29 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// BatchNorm batch statistics -> affine (center only): scale = rstd, shift = beta - mean*rstd.  One definition for the
+// materialising kernel, the normalise-on-load operand path and fn_bn_finalize: replica sums in four interleaved partials
+// (independent loads in flight), combined left to right, so all three produce the same bits.
+__device__ __forceinline__ void bn_batch_affine(const float* __restrict__ stats, int c, int sq_off, int reps, int rep_stride, int count,
+                                                float eps, float beta, float& scale, float& shift, float& mean, float& var) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int rp = 0; rp < reps; rp += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (rp + k < reps) {
+                s[k] += stats[(long)(rp + k) * rep_stride + c];
+                q[k] += stats[(long)(rp + k) * rep_stride + sq_off + c];
+            }
+    }
+    const float s1 = s[0] + s[1] + s[2] + s[3];
+    const float s2 = q[0] + q[1] + q[2] + q[3];
+    const float inv = 1.f / (float)count;
+    mean = s1 * inv;
+    var = fmaxf(s2 * inv - mean * mean, 0.f);
+    scale = rsqrtf(var + eps);
+    shift = beta - mean * scale;
+}
+
 // Bijective XCD-aware remap: blocks b and b+8 share an XCD (and its 4 MiB L2).  Give each XCD a contiguous run of the
 // work-item space; every kernel of the step uses the SAME rows->XCD partition (row fraction x/8 .. (x+1)/8 on XCD x), so
 // what one kernel wrote is still in the L2 of the XCD that reads it in the next kernel (per-XCD L2s are not coherent:

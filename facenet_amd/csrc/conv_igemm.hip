@@ -58,6 +58,11 @@ struct ConvArgs {
     int cp1, cp2, cp3;      // first tile of classes 1..3 (class 0 starts at 0)
     int ny0, ny1, ny2, ny3, nx0, nx1, nx2, nx3;   // pixels per image row / column of every class (scalars: no indexing)
     int total_tiles;
+    // normalise-on-load (forward only): src is the raw output of a BN(center)+ReLU layer, see fn_conv_desc.nrm_*
+    const float* nrm_stats;
+    const float* nrm_beta;
+    int nrm_sq_off, nrm_replicas, nrm_rep_stride, nrm_count;
+    float nrm_eps;
 };
 
 // class mode: taps ky in {qy, qy+2, ..}, kx in {qx, qx+2, ..}
@@ -78,7 +83,7 @@ __device__ __forceinline__ int ktab_entry(int kgroup, int KTOT, int CS, int KW) 
     return (ky << 24) | (kx << 16) | c;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN>
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN, bool NORM>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid) {
     constexpr int BK = 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -124,6 +129,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     const int m0 = tm * BM, n0 = tn * BN;
     const int ntiles_k = (ktot + BK - 1) / BK;
     int* sRow = sK + ((a.KTOT + BK - 1) / BK) * 8;   // [BM] output pixel of every tile row (class mode)
+    float* sNs = reinterpret_cast<float*>(sRow + BM);   // NORM: [CS] scale, [CS] shift of the source channels
+    float* sNh = sNs + a.CS;
+    if constexpr (NORM) {
+        for (int c = tid; c < a.CS; c += 256) {
+            float sc, sh, mean, var;
+            bn_batch_affine(a.nrm_stats, c, a.nrm_sq_off, a.nrm_replicas, a.nrm_rep_stride, a.nrm_count, a.nrm_eps, a.nrm_beta[c], sc, sh,
+                            mean, var);
+            sNs[c] = sc;
+            sNh[c] = sh;
+        }
+    }
 
     if constexpr (!PLAIN) {
         if (a.s2) for (int i = tid; i < ntiles_k * 8; i += 256) sK[i] = ktab_entry_s2(i, a.CS, a.KH, a.KW, qy, qx);
@@ -176,13 +192,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     // Most layers of this network run at <= 1-2 workgroups per CU with cold per-XCD L2s at every kernel start, so
     // nothing else hides the (MALL/HBM) load latency; small tiles have the registers to spare, large grids use DEPTH 1.
     u32x4 ra[DEPTH][AP], rb[DEPTH][BP];   // tile t lives in register stage t % DEPTH
-    auto load_tile = [&](int kt, u32x4 (&ra)[AP], u32x4 (&rb)[BP]) {
+    unsigned rmask[DEPTH];                // NORM: which of the AP rows of a stage hold real pixels (padding must stay zero)
+    auto load_tile = [&](int kt, u32x4 (&ra)[AP], u32x4 (&rb)[BP], unsigned& msk) {
+        msk = 0u;
         if constexpr (PLAIN) {
             const int kk = kt * BK + kg * 8;
 #pragma unroll
             for (int i = 0; i < AP; ++i) {
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (rowy[i] == 0 && kk < a.KTOT) v = *reinterpret_cast<const u32x4*>(a.src + (long)rowbase[i] * a.ld_src + kk);
+                if (rowy[i] == 0 && kk < a.KTOT) {
+                    v = *reinterpret_cast<const u32x4*>(a.src + (long)rowbase[i] * a.ld_src + kk);
+                    msk |= 1u << i;
+                }
                 ra[i] = v;
             }
         } else {
@@ -198,6 +219,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             if (ok) {
                 const long off = (long)(rowbase[i] + sy * a.SW + sx) * a.ld_src + c;
                 v = *reinterpret_cast<const u32x4*>(a.src + off);
+                msk |= 1u << i;
             }
             ra[i] = v;
         }
@@ -217,11 +239,32 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             rb[j] = v;
         }
     };
-    auto store_tile = [&](int buf, const u32x4 (&ra)[AP], const u32x4 (&rb)[BP]) {
+    auto store_tile = [&](int buf, const u32x4 (&ra)[AP], const u32x4 (&rb)[BP], const unsigned msk, const int kt) {
+        float nsc[8], nsh[8];
+        if constexpr (NORM) {   // the 8 source channels of this thread's chunk of tile kt
+            int c = kt * BK + kg * 8;
+            if constexpr (!PLAIN) c = sK[kt * 8 + kg] & 0xffff;
+            if (msk) {
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sNs + c), s1 = *reinterpret_cast<const f32x4*>(sNs + c + 4);
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(sNh + c), h1 = *reinterpret_cast<const f32x4*>(sNh + c + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { nsc[e] = s0[e]; nsc[4 + e] = s1[e]; nsh[e] = h0[e]; nsh[4 + e] = h1[e]; }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int r = r0 + 32 * i;
-            *reinterpret_cast<u32x4*>(sA + buf * A_BYTES + r * 128 + ((kg ^ (r & 7)) << 4)) = ra[i];
+            u32x4 v = ra[i];
+            if constexpr (NORM) {
+                if (msk & (1u << i)) {
+                    float f[8];
+                    unpack8<T>(v, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fmaxf(fmaf(f[e], nsc[e], nsh[e]), 0.f);
+                    v = pack8<T>(f);
+                }
+            }
+            *reinterpret_cast<u32x4*>(sA + buf * A_BYTES + r * 128 + ((kg ^ (r & 7)) << 4)) = v;
         }
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
@@ -261,8 +304,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
-        if (d < ntiles_k) load_tile(d, ra[d], rb[d]);
-    store_tile(0, ra[0], rb[0]);
+        if (d < ntiles_k) load_tile(d, ra[d], rb[d], rmask[d]);
+    store_tile(0, ra[0], rb[0], rmask[0], 0);
     __syncthreads();
     for (int kt0 = 0; kt0 < ntiles_k; kt0 += DEPTH) {
 #pragma unroll
@@ -270,9 +313,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             const int kt = kt0 + d;
             if (kt < ntiles_k) {
                 // stage d held tile kt, already copied to LDS: refill it with tile kt+DEPTH (DEPTH loads stay in flight)
-                if (kt + DEPTH < ntiles_k) load_tile(kt + DEPTH, ra[d], rb[d]);
+                if (kt + DEPTH < ntiles_k) load_tile(kt + DEPTH, ra[d], rb[d], rmask[d]);
                 compute(kt & 1);
-                if (kt + 1 < ntiles_k) store_tile((kt + 1) & 1, ra[(d + 1) % DEPTH], rb[(d + 1) % DEPTH]);
+                if (kt + 1 < ntiles_k) store_tile((kt + 1) & 1, ra[(d + 1) % DEPTH], rb[(d + 1) % DEPTH], rmask[(d + 1) % DEPTH], kt + 1);
                 __syncthreads();
             }
         }
@@ -430,21 +473,21 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN>
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN, bool NORM>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
-    conv_igemm_body<T, BM, BN, WM, WN, DEPTH, PLAIN>(a, blockIdx.x);
+    conv_igemm_body<T, BM, BN, WM, WN, DEPTH, PLAIN, NORM>(a, blockIdx.x);
 }
 
 // Grouped form: one launch runs several INDEPENDENT convolutions of one tile variant (sibling inception towers, the
 // same dependency level of the launch list): args[g] is layer g, prefix[g] .. prefix[g+1] its workgroups.
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN>
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN, bool NORM>
 __global__ __launch_bounds__(256) void conv_igemm_grouped_kernel(const ConvArgs* __restrict__ args, const int* __restrict__ prefix, int n) {
     const int bid = blockIdx.x;
     int g = 0;
     while (g + 1 < n && prefix[g + 1] <= bid) ++g;     // n is small (<= 8)
     g = __builtin_amdgcn_readfirstlane(g);             // provably wave-uniform: args[g] is fetched with scalar loads into SGPRs
     const ConvArgs a = args[g];
-    conv_igemm_body<T, BM, BN, WM, WN, DEPTH, PLAIN>(a, bid - prefix[g]);
+    conv_igemm_body<T, BM, BN, WM, WN, DEPTH, PLAIN, NORM>(a, bid - prefix[g]);
 }
 
 // tiles of a launch; in class mode (stride-2 dgrad) every parity class has its own row tiles
@@ -473,15 +516,15 @@ static void plan_tiles(ConvArgs& a, int BM, int BN) {
     a.total_tiles = t;
 }
 
-static size_t conv_smem_bytes(int BM, int BN, int KTOT) {
+static size_t conv_smem_bytes(int BM, int BN, int KTOT, int norm_channels) {
     const int STAGE = 2 * (BM * 128 + BN * 128);
     const int CB = BM * (BN + 4) * 4;
-    return (size_t)(STAGE > CB ? STAGE : CB) + 2 * BN * 4 + (size_t)cdiv(KTOT, 64) * 8 * 4 + (size_t)BM * 4;
+    return (size_t)(STAGE > CB ? STAGE : CB) + 2 * BN * 4 + (size_t)cdiv(KTOT, 64) * 8 * 4 + (size_t)BM * 4 + (size_t)norm_channels * 8;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN>
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN, bool NORM>
 static int launch_conv_grouped_p(const ConvArgs* dev_args, const int32_t* dev_prefix, int n, int total, size_t smem, hipStream_t st) {
-    auto kern = conv_igemm_grouped_kernel<T, BM, BN, WM, WN, DEPTH, PLAIN>;
+    auto kern = conv_igemm_grouped_kernel<T, BM, BN, WM, WN, DEPTH, PLAIN, NORM>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -491,16 +534,16 @@ static int launch_conv_grouped_p(const ConvArgs* dev_args, const int32_t* dev_pr
     return check_launch("conv_igemm_grouped");
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN>
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN, bool NORM>
 static int launch_conv_p(const ConvArgs& a0, hipStream_t st) {
     ConvArgs a = a0;
     plan_tiles(a, BM, BN);
-    const size_t smem = conv_smem_bytes(BM, BN, a.KTOT);
+    const size_t smem = conv_smem_bytes(BM, BN, a.KTOT, NORM ? a.CS : 0);
     if (smem > 160 * 1024) {
         set_error("conv: K=%d needs %zu B of LDS (>160 KiB)", a.KTOT, smem);
         return FN_EUNSUPPORTED;
     }
-    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, DEPTH, PLAIN>;
+    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, DEPTH, PLAIN, NORM>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -512,7 +555,9 @@ static int launch_conv_p(const ConvArgs& a0, hipStream_t st) {
 
 template <typename T, int BM, int BN, int WM, int WN, int DEPTH>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
-    return a.plain ? launch_conv_p<T, BM, BN, WM, WN, DEPTH, true>(a, st) : launch_conv_p<T, BM, BN, WM, WN, DEPTH, false>(a, st);
+    if (a.nrm_stats)
+        return a.plain ? launch_conv_p<T, BM, BN, WM, WN, DEPTH, true, true>(a, st) : launch_conv_p<T, BM, BN, WM, WN, DEPTH, false, true>(a, st);
+    return a.plain ? launch_conv_p<T, BM, BN, WM, WN, DEPTH, true, false>(a, st) : launch_conv_p<T, BM, BN, WM, WN, DEPTH, false, false>(a, st);
 }
 
 // Tile choice.  BN: smallest padded width, ties -> larger tile.  BM: the largest of {128, 64, 32} that still gives
@@ -555,10 +600,14 @@ template <typename T> static int dispatch_conv(const ConvArgs& a, hipStream_t st
 template <typename T>
 static int dispatch_conv_grouped(const ConvArgs* dev_args, const int32_t* dev_prefix, int n, int total, int bm, int bn, int plain, size_t smem,
                                  hipStream_t st) {
+    const bool norm = (plain & 2) != 0;   // bit 1 of `plain`: every member normalises on load
+    plain &= 1;
 #define FN_X(BM_, BN_, WM_, WN_, D_)                                                                                                  \
     if (bm == BM_ && bn == BN_)                                                                                                       \
-        return plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, true>(dev_args, dev_prefix, n, total, smem, st)               \
-                     : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, false>(dev_args, dev_prefix, n, total, smem, st);
+        return norm ? (plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, true, true>(dev_args, dev_prefix, n, total, smem, st)    \
+                             : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, false, true>(dev_args, dev_prefix, n, total, smem, st))  \
+                    : (plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, true, false>(dev_args, dev_prefix, n, total, smem, st)   \
+                             : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, false, false>(dev_args, dev_prefix, n, total, smem, st));
     FN_CONV_VARIANTS(FN_X)
 #undef FN_X
     set_error("conv_grouped: no tile variant %dx%d", bm, bn);
@@ -595,12 +644,17 @@ struct WgradArgs {
     int gx, gy, splits;  // grid of this layer inside a grouped launch
     int plain;  // 1x1 stride-1: source pixel == output pixel
     float inv_ow, inv_ohw;
+    // normalise-on-load of x (see fn_conv_desc.nrm_*)
+    const float* nrm_stats;
+    const float* nrm_beta;
+    int nrm_sq_off, nrm_replicas, nrm_rep_stride, nrm_count;
+    float nrm_eps;
 };
 
 // k-step pixel permutation shared by both operands: tile row of MFMA k index (g = lane>>4, h = half, q)
 //   rho = q + 4*(g&1) + 8*h + 16*(g>>1)   -> the 8 rows a 32-lane half reads per ds_read_b64_tr_b16
 //   are distinct mod 8, which with row strides of 160 B / 288 B makes the transposed reads conflict free.
-template <typename T, int BMW, int BNW>
+template <typename T, int BMW, int BNW, bool NORM>
 __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bx, const int by, const int bz) {
     constexpr int BK = 64;                   // pixels per stage
     constexpr int DEPTH = (BMW * BNW <= 64 * 64) ? 3 : (BMW * BNW <= 64 * 128 ? 2 : 1);   // register stages in flight
@@ -618,6 +672,8 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bx
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                 // [2][BK][RSA]  dY tile  (rows = pixels, cols = co)
     unsigned char* sB = smem + 2 * A_BYTES;   // [2][BK][RSB]  X  tile  (rows = pixels, cols = kcol)
+    float* sNs = reinterpret_cast<float*>(smem + 2 * (A_BYTES + B_BYTES));   // NORM: [BNW] scale, [BNW] shift of this tile's columns
+    float* sNh = sNs + BNW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WNW, wn = wave % WNW;
@@ -627,6 +683,20 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bx
     const int mend = min(a.M, mbeg + a.chunk);
     const int nst = (mend - mbeg + BK - 1) / BK;
     if (nst <= 0) return;
+    if constexpr (NORM) {
+        if (tid < BNW) {
+            const int e = ktab_entry((n0 >> 3) + (tid >> 3), a.KTOT, a.Cin, a.KW);
+            float sc = 0.f, sh = 0.f, mean, var;
+            if (e >= 0) {
+                const int c = (e & 0xffff) + (tid & 7);
+                bn_batch_affine(a.nrm_stats, c, a.nrm_sq_off, a.nrm_replicas, a.nrm_rep_stride, a.nrm_count, a.nrm_eps, a.nrm_beta[c], sc, sh,
+                                mean, var);
+            }
+            sNs[tid] = sc;
+            sNh[tid] = sh;
+        }
+        __syncthreads();
+    }
 
     // B-operand columns handled by this thread (fixed for the whole kernel)
     int bcol_c[BP], bcol_dy[BP], bcol_dx[BP], brow[BP];
@@ -650,7 +720,9 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bx
     }
 
     u32x4 ra[DEPTH][AP], rb[DEPTH][BP];
-    auto load_tile = [&](int stg, u32x4 (&ra)[AP], u32x4 (&rb)[BP]) {
+    unsigned bmask[DEPTH];   // NORM: which X chunks of a stage hold real pixels
+    auto load_tile = [&](int stg, u32x4 (&ra)[AP], u32x4 (&rb)[BP], unsigned& msk) {
+        msk = 0u;
         const int mb = mbeg + stg * BK;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
@@ -676,12 +748,15 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bx
                     ok = (iy >= 0) && (ix >= 0) && (iy < a.H) && (ix < a.W);
                     pix = (long)(n * a.H + iy) * a.W + ix;
                 }
-                if (ok) v = *reinterpret_cast<const u32x4*>(a.x + pix * a.ld_x + bcol_c[j]);
+                if (ok) {
+                    v = *reinterpret_cast<const u32x4*>(a.x + pix * a.ld_x + bcol_c[j]);
+                    msk |= 1u << j;
+                }
             }
             rb[j] = v;
         }
     };
-    auto store_tile = [&](int buf, const u32x4 (&ra)[AP], const u32x4 (&rb)[BP]) {
+    auto store_tile = [&](int buf, const u32x4 (&ra)[AP], const u32x4 (&rb)[BP], const unsigned msk) {
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int cidx = tid + 256 * i;
@@ -690,7 +765,23 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bx
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
             const int cidx = tid + 256 * j;
-            *reinterpret_cast<u32x4*>(sB + buf * B_BYTES + brow[j] * RSB + (cidx % CGB) * 16) = rb[j];
+            u32x4 v = rb[j];
+            if constexpr (NORM) {
+                if (msk & (1u << j)) {
+                    const int col = (cidx % CGB) * 8;
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sNs + col), s1 = *reinterpret_cast<const f32x4*>(sNs + col + 4);
+                    const f32x4 h0 = *reinterpret_cast<const f32x4*>(sNh + col), h1 = *reinterpret_cast<const f32x4*>(sNh + col + 4);
+                    float f[8];
+                    unpack8<T>(v, f);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        f[e] = fmaxf(fmaf(f[e], s0[e], h0[e]), 0.f);
+                        f[4 + e] = fmaxf(fmaf(f[4 + e], s1[e], h1[e]), 0.f);
+                    }
+                    v = pack8<T>(f);
+                }
+            }
+            *reinterpret_cast<u32x4*>(sB + buf * B_BYTES + brow[j] * RSB + (cidx % CGB) * 16) = v;
         }
     };
 
@@ -731,17 +822,17 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bx
 
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
-        if (d < nst) load_tile(d, ra[d], rb[d]);
-    store_tile(0, ra[0], rb[0]);
+        if (d < nst) load_tile(d, ra[d], rb[d], bmask[d]);
+    store_tile(0, ra[0], rb[0], bmask[0]);
     __syncthreads();
     for (int s0 = 0; s0 < nst; s0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const int stg = s0 + d;
             if (stg < nst) {
-                if (stg + DEPTH < nst) load_tile(stg + DEPTH, ra[d], rb[d]);
+                if (stg + DEPTH < nst) load_tile(stg + DEPTH, ra[d], rb[d], bmask[d]);
                 compute(stg & 1);
-                if (stg + 1 < nst) store_tile((stg + 1) & 1, ra[(d + 1) % DEPTH], rb[(d + 1) % DEPTH]);
+                if (stg + 1 < nst) store_tile((stg + 1) & 1, ra[(d + 1) % DEPTH], rb[(d + 1) % DEPTH], bmask[(d + 1) % DEPTH]);
                 __syncthreads();
             }
         }
@@ -761,16 +852,16 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bx
         }
 }
 
-template <typename T, int BMW, int BNW>
+template <typename T, int BMW, int BNW, bool NORM>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
-    conv_wgrad_body<T, BMW, BNW>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+    conv_wgrad_body<T, BMW, BNW, NORM>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Grouped form: ONE launch computes the weight gradients of many layers.  Weight gradients have no consumer before the
 // optimiser, so the engine defers them to the end of backward and issues them per tile configuration: thousands of
 // workgroups per launch instead of 133 launches that each fill a fraction of the 256 CUs.
 // args[g] describes layer g; prefix[g] .. prefix[g+1] are its workgroups (gx * gy * splits).
-template <typename T, int BMW, int BNW>
+template <typename T, int BMW, int BNW, bool NORM>
 __global__ __launch_bounds__(256) void conv_wgrad_grouped_kernel(const WgradArgs* __restrict__ args, const int* __restrict__ prefix, int n) {
     const int bid = blockIdx.x;
     int lo = 0, hi = n;                    // largest g with prefix[g] <= bid
@@ -783,14 +874,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_grouped_kernel(const WgradArgs
     const int local = bid - prefix[lo];
     const int gxy = a.gx * a.gy;
     const int bz = local / gxy, r = local - bz * gxy;
-    conv_wgrad_body<T, BMW, BNW>(a, r % a.gx, r / a.gx, bz);
+    conv_wgrad_body<T, BMW, BNW, NORM>(a, r % a.gx, r / a.gx, bz);
 }
 
 template <typename T, int BMW, int BNW> static int launch_wgrad(const WgradArgs& a, int splits, hipStream_t st) {
     constexpr int RSA = BMW * 2 + 32, RSB = BNW * 2 + 32;
-    const size_t smem = 2 * 64 * (RSA + RSB);
+    // 64x64 stages are exactly 40 KiB: four workgroups per CU.  Only normalise-on-load launches pay for the affine table.
+    const size_t smem = 2 * 64 * (RSA + RSB) + (a.nrm_stats ? 2 * BNW * 4 : 0);
     dim3 grid(cdiv(a.KTOT, BNW), cdiv(a.Cout, BMW), splits);
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, BMW, BNW>), grid, dim3(256), smem, st, a);
+    if (a.nrm_stats) hipLaunchKernelGGL((conv_wgrad_kernel<T, BMW, BNW, true>), grid, dim3(256), smem, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<T, BMW, BNW, false>), grid, dim3(256), smem, st, a);
     return check_launch("conv_wgrad");
 }
 
@@ -877,6 +970,12 @@ static int make_fwd_args(const fn_conv_desc* d, ConvArgs& a) {
     a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0) ? 1 : 0;
     a.stats_replicas = d->stats_replicas > 0 ? d->stats_replicas : 1;
     a.stats_rep_stride = d->stats_rep_stride;
+    if (d->nrm_stats) {
+        FN_REQUIRE(d->nrm_beta && d->Cin <= 512 && d->nrm_count > 0 && d->nrm_eps > 0.f, "conv_fwd: normalise-on-load needs beta, Cin <= 512, count, eps");
+        a.nrm_stats = d->nrm_stats; a.nrm_beta = d->nrm_beta; a.nrm_sq_off = d->nrm_sq_off;
+        a.nrm_replicas = d->nrm_replicas > 0 ? d->nrm_replicas : 1; a.nrm_rep_stride = d->nrm_rep_stride;
+        a.nrm_count = d->nrm_count; a.nrm_eps = d->nrm_eps;
+    }
     return FN_OK;
 }
 
@@ -938,12 +1037,13 @@ extern "C" int fn_conv2d_group_build(const fn_conv_desc* descs, int n, int op, i
         choose_conv_tile(a.M, a.NOUT, m, k);
         FN_REQUIRE(m == bm && k == bn, "conv_group_build: descriptor %d dispatches to %dx%d, group is %dx%d", i, m, k, bm, bn);
         FN_REQUIRE(descs[i].dtype == descs[0].dtype, "conv_group_build: mixed dtypes");
-        if (plain0 < 0) plain0 = a.plain;
-        FN_REQUIRE(a.plain == plain0, "conv_group_build: 1x1 and general convolutions cannot share a group");
+        const int pl = a.plain | (a.nrm_stats ? 2 : 0);
+        if (plain0 < 0) plain0 = pl;
+        FN_REQUIRE(pl == plain0, "conv_group_build: 1x1 / general / normalise-on-load convolutions cannot share a group");
         plan_tiles(a, bm, bn);
         host_prefix[i] = (int32_t)total;
         total += (long)a.total_tiles;
-        const size_t sm = conv_smem_bytes(bm, bn, a.KTOT);
+        const size_t sm = conv_smem_bytes(bm, bn, a.KTOT, a.nrm_stats ? a.CS : 0);
         if (sm > smem) smem = sm;
         out[i] = a;
     }
@@ -975,6 +1075,12 @@ static int make_wgrad_args(const fn_conv_desc* d, WgradArgs& a) {
     a.ld_x = d->ld_x; a.ld_y = d->ld_y;
     a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0) ? 1 : 0;
     a.inv_ow = 1.0f / (float)d->OW; a.inv_ohw = 1.0f / (float)(d->OH * d->OW);
+    if (d->nrm_stats) {
+        FN_REQUIRE(d->nrm_beta && d->nrm_count > 0 && d->nrm_eps > 0.f, "conv_wgrad: normalise-on-load needs beta, count, eps");
+        a.nrm_stats = d->nrm_stats; a.nrm_beta = d->nrm_beta; a.nrm_sq_off = d->nrm_sq_off;
+        a.nrm_replicas = d->nrm_replicas > 0 ? d->nrm_replicas : 1; a.nrm_rep_stride = d->nrm_rep_stride;
+        a.nrm_count = d->nrm_count; a.nrm_eps = d->nrm_eps;
+    }
     return FN_OK;
 }
 
@@ -992,6 +1098,8 @@ extern "C" int fn_conv2d_wgrad_arg_bytes(void) { return (int)sizeof(WgradArgs); 
 // dispatch to `variant` (= fn_conv2d_variant(desc, 2)); returns the total number of workgroups (or a negative status).
 extern "C" int fn_conv2d_wgrad_group_build(const fn_conv_desc* descs, int n, int variant, void* host_args, int32_t* host_prefix) {
     FN_REQUIRE(descs && host_args && host_prefix && n > 0, "wgrad_group_build: bad arguments");
+    const bool norm = variant >= 1000000;
+    variant %= 1000000;
     const int bmw = variant / 1000, bnw = variant % 1000;
     WgradArgs* out = reinterpret_cast<WgradArgs*>(host_args);
     long total = 0;
@@ -1002,6 +1110,7 @@ extern "C" int fn_conv2d_wgrad_group_build(const fn_conv_desc* descs, int n, int
         final_wgrad_tile(a.Cout, a.KTOT, m, k);
         FN_REQUIRE(m == bmw && k == bnw, "wgrad_group_build: descriptor %d dispatches to %dx%d, group is %dx%d", i, m, k, bmw, bnw);
         FN_REQUIRE(descs[i].dtype == descs[0].dtype, "wgrad_group_build: mixed dtypes");
+        FN_REQUIRE((a.nrm_stats != nullptr) == norm, "wgrad_group_build: descriptor %d: normalise-on-load members need a group of their own (variant + 1000000)", i);
         const int splits = plan_wgrad(a, descs[i].splits, bmw, bnw, true);
         host_prefix[i] = (int32_t)total;
         total += (long)a.gx * a.gy * splits;
@@ -1013,11 +1122,15 @@ extern "C" int fn_conv2d_wgrad_group_build(const fn_conv_desc* descs, int n, int
 }
 
 template <typename T> static int launch_wgrad_grouped(const void* args, const int32_t* prefix, int n, int total, int variant, hipStream_t st) {
+    const bool norm = variant >= 1000000;     // +1000000: every member normalises x on load
+    variant %= 1000000;
     const int bmw = variant / 1000, bnw = variant % 1000;
     const WgradArgs* a = reinterpret_cast<const WgradArgs*>(args);
 #define FN_WG(BM_, BN_)                                                                                                     \
     if (bmw == BM_ && bnw == BN_) {                                                                                         \
-        hipLaunchKernelGGL((conv_wgrad_grouped_kernel<T, BM_, BN_>), dim3(total), dim3(256), 2 * 64 * ((BM_) * 2 + 32 + (BN_) * 2 + 32), st, a, prefix, n); \
+        const size_t sm_ = 2 * 64 * ((BM_) * 2 + 32 + (BN_) * 2 + 32) + (norm ? 2 * (BN_) * 4 : 0);                            \
+        if (norm) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<T, BM_, BN_, true>), dim3(total), dim3(256), sm_, st, a, prefix, n); \
+        else hipLaunchKernelGGL((conv_wgrad_grouped_kernel<T, BM_, BN_, false>), dim3(total), dim3(256), sm_, st, a, prefix, n);    \
         return check_launch("conv_wgrad_grouped");                                                                          \
     }
     FN_WG(32, 64) FN_WG(32, 128) FN_WG(64, 64) FN_WG(64, 128) FN_WG(128, 64) FN_WG(128, 128)

@@ -735,6 +735,31 @@ extern "C" int fn_gather_images(const uint8_t* pool, const int32_t* idx, uint8_t
     return check_launch("gather_images");
 }
 
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int sq_off, int rep_stride, const int* __restrict__ reps,
+                                                          const int* __restrict__ count, const float* __restrict__ beta,
+                                                          float* __restrict__ save_scale, float* __restrict__ save_shift,
+                                                          float* __restrict__ mm, float* __restrict__ mv, float momentum, float eps, int CB) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= CB || reps[c] <= 0) return;
+    float sc, sh, mean, var;
+    bn_batch_affine(stats, c, sq_off, reps[c], rep_stride, count[c], eps, beta[c], sc, sh, mean, var);
+    save_scale[c] = sc;
+    save_shift[c] = sh;
+    if (mm) {
+        mm[c] = mm[c] * momentum + mean * (1.f - momentum);
+        mv[c] = mv[c] * momentum + var * (1.f - momentum);
+    }
+}
+
+extern "C" int fn_bn_finalize(const float* stats, int sq_off, int rep_stride, const int32_t* reps, const int32_t* count, const float* beta,
+                              float* save_scale, float* save_shift, float* moving_mean, float* moving_var, float momentum, float eps, int CB,
+                              void* stream) {
+    FN_REQUIRE(stats && reps && count && beta && save_scale && save_shift && CB > 0 && (!moving_mean == !moving_var), "bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(CB, 256)), dim3(256), 0, (hipStream_t)stream, stats, sq_off, rep_stride, reps, count, beta,
+                       save_scale, save_shift, moving_mean, moving_var, momentum, eps, CB);
+    return check_launch("bn_finalize");
+}
+
 extern "C" int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, int M, int C, const float* stats, int stats_sq_off,
                                     int stats_replicas, int stats_rep_stride, const float* beta,
                                     float* save_scale, float* save_shift, float* moving_mean, float* moving_var, float momentum, float eps,

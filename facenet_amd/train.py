@@ -55,7 +55,7 @@ def group_wgrads(ops: List[Op], net: Network) -> List[Op]:
     groups = {}
     for op in singles:
         d = op.keep[0]
-        groups.setdefault((lib.fn_conv2d_variant(C.byref(d), 2), d.dtype), []).append(op)
+        groups.setdefault((lib.fn_conv2d_variant(C.byref(d), 2) + (1000000 if d.nrm_stats else 0), d.dtype), []).append(op)
     nbytes = lib.fn_conv2d_wgrad_arg_bytes()
     out = list(rest)
     for (variant, dt), members in sorted(groups.items()):
@@ -72,7 +72,8 @@ def group_wgrads(ops: List[Op], net: Network) -> List[Op]:
         for m in members:
             reads.extend(m.reads)
             writes.extend(m.writes)
-        out.append(Op(f"conv_wgrad_grouped:{variant // 1000}x{variant % 1000}", lib.fn_conv2d_wgrad_grouped,
+        out.append(Op(f"conv_wgrad_grouped:{variant % 1000000 // 1000}x{variant % 1000}" + (":norm" if variant >= 1000000 else ""),
+                      lib.fn_conv2d_wgrad_grouped,
                       (_ptr(dev_args), _ptr(dev_prefix), n, total, variant, dt), keep=(descs, dev_args, dev_prefix, members),
                       reads=tuple(reads), writes=tuple(writes)))
     return out
@@ -94,6 +95,8 @@ def group_convs(ops: List[Op], net: Network) -> List[Op]:
             d = op.keep[0]
             opi = 0 if kind == "conv_fwd" else 1
             plain = int(d.KH == 1 and d.KW == 1 and d.stride == 1 and d.pad_h == 0 and d.pad_w == 0)
+            if opi == 0 and d.nrm_stats:
+                plain |= 2                           # normalise-on-load members form their own groups
             buckets.setdefault((level[i], opi, lib.fn_conv2d_variant(C.byref(d), opi), plain, d.dtype), []).append(i)
     fused_at, skip = {}, set()
     for (lv, opi, variant, plain, dt), idxs in buckets.items():

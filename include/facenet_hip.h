@@ -64,6 +64,16 @@ typedef struct fn_conv_desc {
     const float* bn_beta;
     float* bn_acc;
     int32_t ld_bn_y, bn_sq_off, bn_replicas, bn_rep_stride, bn_relu;
+    /* fwd / wgrad: "normalise on load".  When nrm_stats is set, x is the RAW output of a BatchNormalization(center only)+ReLU
+     * layer whose batch statistics (sum | sum of squares, replicated like `stats`) have been accumulated by the producing
+     * fn_conv2d_fwd; the operand the convolution sees is relu((x - mean) * rstd + beta), computed per element while the tile
+     * is staged (zero padding stays zero).  The activated tensor is then never written.  Index 0 of nrm_stats / nrm_beta
+     * is channel 0 of x; nrm_count = N*H*W of x.  Cin <= 512.  fn_bn_finalize publishes the same scale / shift for the
+     * backward pass and updates the moving statistics. */
+    const float* nrm_stats;
+    const float* nrm_beta;
+    int32_t nrm_sq_off, nrm_replicas, nrm_rep_stride, nrm_count;
+    float nrm_eps;
 } fn_conv_desc;
 
 int fn_conv2d_fwd(const fn_conv_desc* d, void* stream);
@@ -78,7 +88,9 @@ int fn_conv2d_grouped(const void* dev_args, const int32_t* dev_prefix, int n, in
 /* Grouped weight gradients: one launch for many layers that share a tile variant (= fn_conv2d_variant(d, 2)).
  * fn_conv2d_wgrad_group_build plans on the HOST: it fills host_args (n * fn_conv2d_wgrad_arg_bytes() bytes, opaque) and
  * host_prefix (n+1 workgroup offsets) and returns the total workgroup count; the caller copies both to device memory once and
- * replays fn_conv2d_wgrad_grouped every step (pointers inside the descriptors must stay valid). */
+ * replays fn_conv2d_wgrad_grouped every step (pointers inside the descriptors must stay valid).  Members that normalise x
+ * on load (nrm_stats) form groups of their own: pass variant + 1000000 to both calls.  Likewise fn_conv2d_grouped takes
+ * plain | 2 for a group whose members all normalise on load. */
 int fn_conv2d_wgrad_arg_bytes(void);
 int fn_conv2d_wgrad_group_build(const fn_conv_desc* descs, int n, int variant, void* host_args, int32_t* host_prefix);
 int fn_conv2d_wgrad_grouped(const void* dev_args, const int32_t* dev_prefix, int n, int total_blocks, int variant, int dtype, void* stream);
@@ -100,6 +112,13 @@ int fn_image_resize_bilinear(const void* img, int src_is_f32, float* out, int N,
 int fn_crop_or_pad_u8(const uint8_t* src, const long long* offsets, const int32_t* hw, uint8_t* dst, int N, int S, void* stream);
 /* gather rows of a u8 image pool by index (triplet batch assembly): out[i] = pool[idx[i]] */
 int fn_gather_images(const uint8_t* pool, const int32_t* idx, uint8_t* out, int n_out, int bytes_per_image, void* stream);
+
+/* Batched finalisation for the layers consumed through nrm_* (no fn_bn_relu_train_fwd launch): for every channel c < CB with
+ * reps[c] > 0: mean/var from the replicated sums (count[c] elements), save_scale = rstd, save_shift = beta - mean*rstd,
+ * moving statistics updated as in fn_bn_relu_train_fwd.  One launch for the whole network. */
+int fn_bn_finalize(const float* stats, int sq_off, int rep_stride, const int32_t* reps, const int32_t* count, const float* beta,
+                   float* save_scale, float* save_shift, float* moving_mean, float* moving_var, float momentum, float eps, int CB,
+                   void* stream);
 
 /* ---- BatchNormalization (center only, no scale; eps 1e-3, momentum 0.99) --------
  * inception_resnet_v1.py:56-63 and every BatchNormalization(**...) line; ReLU() fused.

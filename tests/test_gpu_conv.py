@@ -227,3 +227,75 @@ def test_dgrad_fused_bn_backward_reduction(lib, dt):
     assert rel_err(acc.sum(0), acc_ref) < tol
     assert rel_err(dbeta, dbeta_ref) < tol
     assert rel_err(dx, dx_ref) < tol
+
+
+NORM_CASES = [c for c in CASES if c[3] <= 512 and c[3] >= 32]
+
+
+@pytest.mark.parametrize("dt", [_lib.FN_BF16, _lib.FN_F16])
+@pytest.mark.parametrize("case", NORM_CASES)
+def test_conv_normalise_on_load_equals_materialised_bn(lib, case, dt):
+    """fwd and wgrad with nrm_* on the RAW tensor must give exactly what they give on the tensor fn_bn_relu_train_fwd writes
+    (same statistics, same rounding of the activated operand), including zero padding and channel slices."""
+    N, H, W, Cin, Cout, kh, kw, s, ph, pw = case
+    M = N * H * W
+    ld = Cin + 16                                      # x is the slice [8, 8+Cin) of a wider buffer
+    raw = _mk((N, H, W, ld), dt, 1.5, seed=11)
+    rawf = raw[..., 8:8 + Cin].float().reshape(M, Cin)
+    reps, CBs = 4, Cin + 24                            # statistics live at offset 16 of a wider channel space
+    stats = torch.zeros(reps, 2 * CBs, dtype=torch.float32, device="cuda")
+    part = torch.arange(M, device="cuda") % reps
+    for r in range(reps):                              # replicas hold partial sums, as the producing conv leaves them
+        stats[r, 16:16 + Cin] = rawf[part == r].sum(0)
+        stats[r, CBs + 16:CBs + 16 + Cin] = (rawf[part == r] ** 2).sum(0)
+    beta = (torch.randn(CBs, generator=torch.Generator().manual_seed(5)) * 0.3).cuda()
+    z = torch.zeros_like(raw)
+    sc, sh = torch.zeros(CBs, device="cuda"), torch.zeros(CBs, device="cuda")
+    _lib.check(lib.fn_bn_relu_train_fwd(ptr(raw, 8), ld, ptr(z, 8), ld, M, Cin, ptr(stats, 16), CBs, reps, 2 * CBs, ptr(beta, 16),
+                                        ptr(sc, 16), ptr(sh, 16), None, None, 0.99, 1e-3, 1, dt, stream()))
+    w = _mk((Cout, kh, kw, Cin), dt, 0.1, seed=12)
+    outs = []
+    for norm in (False, True):
+        d = conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt, ld_x=ld)
+        y = torch.zeros(N, d.OH, d.OW, Cout, dtype=lp_dtype(dt), device="cuda")
+        d.w, d.y = ptr(w), ptr(y)
+        if norm:
+            d.x, d.nrm_stats, d.nrm_beta = ptr(raw, 8), ptr(stats, 16), ptr(beta, 16)
+            d.nrm_sq_off, d.nrm_replicas, d.nrm_rep_stride, d.nrm_count, d.nrm_eps = CBs, reps, 2 * CBs, M, 1e-3
+        else:
+            d.x = ptr(z, 8)
+        _lib.check(lib.fn_conv2d_fwd(C.byref(d), stream()))
+        dy = _mk((N, d.OH, d.OW, Cout), dt, seed=13)
+        dw = torch.zeros(Cout, kh * kw * Cin, dtype=torch.float32, device="cuda")
+        d.y, d.dw, d.splits = ptr(dy), ptr(dw), 1      # one split: the accumulation order is fixed, results comparable bit for bit
+        _lib.check(lib.fn_conv2d_wgrad(C.byref(d), stream()))
+        torch.cuda.synchronize()
+        outs.append((y, dw))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].float().abs().max()) > 0 and float(outs[0][1].abs().max()) > 0
+    # fn_bn_finalize publishes the same scale / shift and moving statistics as the materialising kernel
+    sc2, sh2 = torch.zeros(CBs, device="cuda"), torch.zeros(CBs, device="cuda")
+    mm, mv = torch.zeros(CBs, device="cuda"), torch.ones(CBs, device="cuda")
+    mm_ref, mv_ref = torch.zeros(CBs, device="cuda"), torch.ones(CBs, device="cuda")
+    _lib.check(lib.fn_bn_relu_train_fwd(ptr(raw, 8), ld, ptr(z, 8), ld, M, Cin, ptr(stats, 16), CBs, reps, 2 * CBs, ptr(beta, 16),
+                                        ptr(sc, 16), ptr(sh, 16), ptr(mm_ref, 16), ptr(mv_ref, 16), 0.99, 1e-3, 1, dt, stream()))
+    fr = torch.zeros(CBs, dtype=torch.int32, device="cuda")
+    fr[16:16 + Cin] = reps
+    fc = torch.full((CBs,), M, dtype=torch.int32, device="cuda")
+    _lib.check(lib.fn_bn_finalize(ptr(stats), CBs, 2 * CBs, ptr(fr), ptr(fc), ptr(beta), ptr(sc2), ptr(sh2), ptr(mm), ptr(mv), 0.99, 1e-3, CBs,
+                                  stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(sc, sc2) and torch.equal(sh, sh2) and torch.equal(mm, mm_ref) and torch.equal(mv, mv_ref)
+    assert float(sc2[:16].abs().max()) == 0 and float(sc2[16 + Cin:].abs().max()) == 0      # channels with reps == 0 untouched
+
+
+def test_conv_normalise_on_load_rejects_wide_inputs(lib):
+    d = conv_desc(1, 3, 3, 1792, 128, 1, 1, 1, 0, 0, _lib.FN_BF16)
+    x = torch.zeros(1, 3, 3, 1792, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(128, 1, 1, 1792, dtype=torch.bfloat16, device="cuda")
+    y = torch.zeros(1, 3, 3, 128, dtype=torch.bfloat16, device="cuda")
+    st = torch.zeros(2 * 1792, device="cuda")
+    d.x, d.w, d.y, d.nrm_stats, d.nrm_beta, d.nrm_count, d.nrm_eps, d.nrm_sq_off = ptr(x), ptr(w), ptr(y), ptr(st), ptr(st), 9, 1e-3, 1792
+    with pytest.raises(ValueError):
+        _lib.check(lib.fn_conv2d_fwd(C.byref(d), stream()))

@@ -193,3 +193,30 @@ def test_scheduled_multistream_step_matches_serial_replay():
         print(name, d)
         assert d[0] <= 3 * floor[0] + 2e-3 and d[1] <= 3 * floor[1] + 2e-3 and d[2] <= 3 * floor[2] + 2e-2, name
         assert d[3] <= 3 * floor[3] + 2.5e-2                 # one Adam step moves a weight by at most ~lr
+
+
+def test_normalise_on_load_plan_matches_materialised_plan(monkeypatch):
+    """The optional plan that never writes the BN+ReLU tensors (consumers normalise the raw tensor while staging it) must
+    reproduce the default plan's step up to the run-to-run noise floor; it launches 78 fewer bn_relu_fwd kernels."""
+    from tests.util import structured_images
+    E, N = 128, 6
+    params, _, _ = fo.build_params(E, seed=0)
+    x = torch.from_numpy(structured_images(N, seed=7))
+    results, launches = [], []
+    for mode in ("0", "0", "1"):
+        monkeypatch.setenv("FACENET_NORM_ON_LOAD", mode)
+        net = Network(embedding_size=E, device="cuda:0", train_dtype=torch.float16)
+        net.load_keras_params(params)
+        tr = Trainer(net, batch=N, loss="triplet", alpha=0.2, lr=0.01)
+        tr.set_images(x)
+        tr.step_eager()
+        torch.cuda.synchronize()
+        results.append((tr.loss_value(), tr.emb.clone(), tr.G.clone(), net.P.clone(), net.S_mean.clone(), net.S_var.clone()))
+        launches.append(sum(1 for op in tr.plan.fwd if op.name.startswith("bn_relu_fwd")))
+        assert bool(tr.plan.virtual) == (mode == "1")
+    assert launches[0] - launches[2] == 78 and any(op.name == "bn_finalize" for op in tr.plan.fwd)
+    floor = (_rel(results[1][1], results[0][1]), _rel(results[1][2], results[0][2]))
+    d = (_rel(results[2][1], results[0][1]), _rel(results[2][2], results[0][2]))
+    print("noise floor (emb, grad):", floor, " normalise-on-load vs default:", d)
+    assert d[0] <= 3 * floor[0] + 2e-3 and d[1] <= 3 * floor[1] + 2e-2
+    assert torch.allclose(results[2][4], results[0][4], rtol=1e-3, atol=1e-4) and torch.allclose(results[2][5], results[0][5], rtol=1e-3, atol=1e-4)
