@@ -30,6 +30,14 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 enum { DT_BF16 = 0, DT_F16 = 1 };
 
+// Pointers that a kernel reads out of a descriptor table in memory (grouped launches) have no known address space, and the
+// compiler falls back to FLAT loads.  Those count on lgkmcnt as well as vmcnt, so every wait for an LDS read also drains
+// the global loads in flight.  Hot-loop loads go through explicitly global pointers.
+#define FN_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ u32x4 load_global_b128(const unsigned short* base, long elem_off) {
+    return *(const FN_GLOBAL u32x4*)((const FN_GLOBAL unsigned short*)base + elem_off);
+}
+
 template <typename T> struct LP;  // low-precision traits
 template <> struct LP<__bf16> {
     typedef bf16x8 vec8;
@@ -76,8 +84,9 @@ template <typename T> __device__ __forceinline__ u32x4 pack8(const float (&f)[8]
 __device__ __forceinline__ void fast_divmod(int m, int d, float inv, int& q, int& r) {
     q = (int)((float)m * inv);
     r = m - q * d;
-    if (r < 0) { r += d; --q; }
-    else if (r >= d) { r -= d; ++q; }
+    const int lo = r < 0 ? 1 : 0, hi = r >= d ? 1 : 0;   // branch-free fix-up (a branch here ends up around the loads that follow)
+    q += hi - lo;
+    r += (lo - hi) * d;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -58,6 +58,7 @@ struct ConvArgs {
     int cp1, cp2, cp3;      // first tile of classes 1..3 (class 0 starts at 0)
     int ny0, ny1, ny2, ny3, nx0, nx1, nx2, nx3;   // pixels per image row / column of every class (scalars: no indexing)
     int total_tiles;
+    int src_bytes, w_bytes;   // extents for the buffer resource descriptors (< 2^30)
     // normalise-on-load (forward only): src is the raw output of a BN(center)+ReLU layer, see fn_conv_desc.nrm_*
     const float* nrm_stats;
     const float* nrm_beta;
@@ -101,7 +102,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     unsigned char* sB = smem + 2 * A_BYTES;
     float* sC = reinterpret_cast<float*>(smem);
     float* sRed = reinterpret_cast<float*>(smem + MAIN_BYTES);         // [2*BN]
-    int* sK = reinterpret_cast<int*>(smem + MAIN_BYTES + 2 * BN * 4);  // [ceil(KTOT/64)*8]
+    int4* sT = reinterpret_cast<int4*>(smem + MAIN_BYTES + 2 * BN * 4);  // tap table [ceil(KTOT/64)*8] (general convolutions)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -128,7 +129,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int ntiles_k = (ktot + BK - 1) / BK;
-    int* sRow = sK + ((a.KTOT + BK - 1) / BK) * 8;   // [BM] output pixel of every tile row (class mode)
+    int* sRow = reinterpret_cast<int*>(sT + (PLAIN ? 0 : ((a.KTOT + BK - 1) / BK) * 8));   // [BM] output pixel of every tile row (class mode)
     float* sNs = reinterpret_cast<float*>(sRow + BM);   // NORM: [CS] scale, [CS] shift of the source channels
     float* sNh = sNs + a.CS;
     if constexpr (NORM) {
@@ -141,109 +142,109 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         }
     }
 
+    // Operand addressing.  Both operands are read with BUFFER loads (32-bit byte offsets against a resource descriptor):
+    // an offset at or beyond num_records returns zeros without touching memory, so padding, ragged rows / columns and the
+    // K tail cost no select and no mask, and the loads are unconditional (the compiler can count what is in flight and
+    // keeps DEPTH stages outstanding instead of draining the queue at every stage).  OOB + anything this kernel adds to it
+    // stays >= 2^30 > num_records (the host checks the extents).
+    //   A row i of this thread : ry/rx = source coordinates of tap (0,0), rbyte = byte offset of that pixel (or OOB)
+    //   tap-table entry (kt,kg): x = dy<<24 | dx<<16 | c, y = byte delta of the tap (or OOB), z = byte offset of the weight column
+    // Class mode (stride-2 dgrad): coordinates are in units of 2 source pixels; parity is guaranteed by the class.
+    constexpr unsigned OOB = 0x60000000u;
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.src), 0, a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, a.w_bytes, 0x00020000);
     if constexpr (!PLAIN) {
-        if (a.s2) for (int i = tid; i < ntiles_k * 8; i += 256) sK[i] = ktab_entry_s2(i, a.CS, a.KH, a.KW, qy, qx);
-        else for (int i = tid; i < ntiles_k * 8; i += 256) sK[i] = ktab_entry(i, a.KTOT, a.CS, a.KW);
+        for (int i = tid; i < ntiles_k * 8; i += 256) {
+            const int e = a.s2 ? ktab_entry_s2(i, a.CS, a.KH, a.KW, qy, qx) : ktab_entry(i, a.KTOT, a.CS, a.KW);
+            int4 t = make_int4(0, (int)OOB, (int)OOB, 0);
+            if (e >= 0) {
+                const int ky = (e >> 24) & 0xff, kx = (e >> 16) & 0xff, c = e & 0xffff;
+                const int dy = a.s2 ? -((ky - qy) >> 1) : ky * a.sk, dx = a.s2 ? -((kx - qx) >> 1) : kx * a.sk;
+                t.x = (int)(((unsigned)(dy & 0xff) << 24) | ((unsigned)(dx & 0xff) << 16) | (unsigned)c);
+                t.y = ((dy * a.SW + dx) * a.ld_src + c) * 2;
+                t.z = ((ky * a.KW + kx) * a.CS + c) * 2;
+            }
+            sT[i] = t;
+        }
     }
     if (tid < 2 * BN) sRed[tid] = 0.f;
 
-    // per-thread gather rows
     const int kg = tid & 7, r0 = tid >> 3;
-    int rowy[AP], rowx[AP], rowbase[AP];
+    int ry[AP], rx[AP];
+    unsigned rbyte[AP], wbyte[BP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int m = m0 + r0 + 32 * i;
+        ry[i] = 0;
+        rx[i] = 0;
+        rbyte[i] = OOB;
         if constexpr (PLAIN) {
-            rowy[i] = (m < a.M) ? 0 : -1;
-            rowx[i] = 0;
-            rowbase[i] = m;
+            if (m < a.M) rbyte[i] = (unsigned)m * (unsigned)a.ld_src * 2u;
         } else if (a.s2) {
             if (m < cls_M) {
                 const int ny = cny, nx = cnx;
                 const int n = m / (ny * nx), rem = m - n * ny * nx;
                 const int j = rem / nx, ii = rem - j * nx;
                 const int py = 2 * j + ((qy - a.offy) & 1), px = 2 * ii + ((qx - a.offx) & 1);   // (py + pad) & 1 == qy
-                rowy[i] = py + a.offy;
-                rowx[i] = px + a.offx;
-                rowbase[i] = n * a.SH * a.SW;
+                ry[i] = (py + a.offy - qy) >> 1;     // taps of the class sit at ry - (ky - qy)/2
+                rx[i] = (px + a.offx - qx) >> 1;
+                rbyte[i] = (unsigned)(((n * a.SH + ry[i]) * a.SW + rx[i]) * a.ld_src) * 2u;
                 if (kg == 0) sRow[r0 + 32 * i] = (n * a.PH + py) * a.PW + px;
-            } else {
-                rowy[i] = -(1 << 28);
-                rowx[i] = 0;
-                rowbase[i] = 0;
-                if (kg == 0) sRow[r0 + 32 * i] = -1;
+            } else if (kg == 0) {
+                sRow[r0 + 32 * i] = -1;
             }
         } else if (m < a.M) {
             const int n = m / (a.PH * a.PW), rem = m - n * a.PH * a.PW;
             const int py = rem / a.PW, px = rem - py * a.PW;
-            rowy[i] = py * a.so + a.offy;
-            rowx[i] = px * a.so + a.offx;
-            rowbase[i] = n * a.SH * a.SW;
-        } else {
-            rowy[i] = -(1 << 28);  // never valid
-            rowx[i] = 0;
-            rowbase[i] = 0;
+            ry[i] = py * a.so + a.offy;
+            rx[i] = px * a.so + a.offx;
+            rbyte[i] = (unsigned)(((n * a.SH + ry[i]) * a.SW + rx[i]) * a.ld_src) * 2u;
         }
     }
-    const int dmask = (1 << a.dshift) - 1;
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+        const int co = n0 + r0 + 32 * j;
+        wbyte[j] = co < a.NOUT ? (unsigned)co * (unsigned)a.KTOT * 2u : OOB;
+    }
     __syncthreads();
 
     // DEPTH register stages: while tile kt is multiplied out of LDS, tiles kt+1 .. kt+DEPTH are loaded or in flight.
     // Most layers of this network run at <= 1-2 workgroups per CU with cold per-XCD L2s at every kernel start, so
     // nothing else hides the (MALL/HBM) load latency; small tiles have the registers to spare, large grids use DEPTH 1.
     u32x4 ra[DEPTH][AP], rb[DEPTH][BP];   // tile t lives in register stage t % DEPTH
-    unsigned rmask[DEPTH];                // NORM: which of the AP rows of a stage hold real pixels (padding must stay zero)
+    unsigned rmask[DEPTH];                // NORM only: A rows of a stage that hold real pixels (padding must stay zero)
     auto load_tile = [&](int kt, u32x4 (&ra)[AP], u32x4 (&rb)[BP], unsigned& msk) {
-        msk = 0u;
+        unsigned mk = 0u;
         if constexpr (PLAIN) {
             const int kk = kt * BK + kg * 8;
+            const unsigned kb = kk < a.KTOT ? (unsigned)kk * 2u : OOB;
 #pragma unroll
             for (int i = 0; i < AP; ++i) {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (rowy[i] == 0 && kk < a.KTOT) {
-                    v = *reinterpret_cast<const u32x4*>(a.src + (long)rowbase[i] * a.ld_src + kk);
-                    msk |= 1u << i;
-                }
-                ra[i] = v;
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, (int)(rbyte[i] + kb), 0, 0);
+                if constexpr (NORM) mk |= ((rbyte[i] + kb) < 0x40000000u ? 1u : 0u) << i;
             }
+#pragma unroll
+            for (int j = 0; j < BP; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wbyte[j] + kb), 0, 0);
         } else {
-        const int e = sK[kt * 8 + kg];
-        const int ky = (e >> 24) & 0xff, kx = (e >> 16) & 0xff, c = e & 0xffff;
-        const int dy = ky * a.sk, dx = kx * a.sk;
+            const int4 t = sT[kt * 8 + kg];
+            const int dy = t.x >> 24, dx = (int)((unsigned)t.x << 8) >> 24;
 #pragma unroll
-        for (int i = 0; i < AP; ++i) {
-            const int ty = rowy[i] + dy, tx = rowx[i] + dx;
-            const int sy = ty >> a.dshift, sx = tx >> a.dshift;
-            const bool ok = (e >= 0) && (ty >= 0) && (tx >= 0) && (((ty | tx) & dmask) == 0) && (sy < a.SH) && (sx < a.SW);
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) {
-                const long off = (long)(rowbase[i] + sy * a.SW + sx) * a.ld_src + c;
-                v = *reinterpret_cast<const u32x4*>(a.src + off);
-                msk |= 1u << i;
+            for (int i = 0; i < AP; ++i) {
+                const bool ok = (unsigned)(ry[i] + dy) < (unsigned)a.SH && (unsigned)(rx[i] + dx) < (unsigned)a.SW;
+                const unsigned off = ok ? rbyte[i] + (unsigned)t.y : OOB;
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, (int)off, 0, 0);
+                if constexpr (NORM) mk |= (off < 0x40000000u ? 1u : 0u) << i;
             }
-            ra[i] = v;
-        }
-        }
-        int k = kt * BK + kg * 8;
-        bool kok = k < ktot;
-        if constexpr (!PLAIN) {
-            const int e2 = sK[kt * 8 + kg];   // weight column of this k group: (ky*KW + kx)*CS + c
-            kok = e2 >= 0;
-            k = ((((e2 >> 24) & 0xff) * a.KW + ((e2 >> 16) & 0xff)) * a.CS) + (e2 & 0xffff);
-        }
 #pragma unroll
-        for (int j = 0; j < BP; ++j) {
-            const int co = n0 + r0 + 32 * j;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (co < a.NOUT && kok) v = *reinterpret_cast<const u32x4*>(a.wp + (long)co * a.KTOT + k);
-            rb[j] = v;
+            for (int j = 0; j < BP; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wbyte[j] + (unsigned)t.z), 0, 0);
         }
+        msk = mk;
     };
     auto store_tile = [&](int buf, const u32x4 (&ra)[AP], const u32x4 (&rb)[BP], const unsigned msk, const int kt) {
         float nsc[8], nsh[8];
         if constexpr (NORM) {   // the 8 source channels of this thread's chunk of tile kt
             int c = kt * BK + kg * 8;
-            if constexpr (!PLAIN) c = sK[kt * 8 + kg] & 0xffff;
+            if constexpr (!PLAIN) c = sT[kt * 8 + kg].x & 0xffff;
             if (msk) {
                 const f32x4 s0 = *reinterpret_cast<const f32x4*>(sNs + c), s1 = *reinterpret_cast<const f32x4*>(sNs + c + 4);
                 const f32x4 h0 = *reinterpret_cast<const f32x4*>(sNh + c), h1 = *reinterpret_cast<const f32x4*>(sNh + c + 4);
@@ -302,20 +303,23 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         }
     };
 
+    // Steady state without branches around loads (same reason as above: a conditional load makes the compiler drain the
+    // queue).  Tile indices are clamped to the last tile, so the tail re-loads it (L2 hits) and up to DEPTH-1 trailing
+    // iterations only move data; nothing reads what they stage.
+    if (ntiles_k > 0) {
+        const int last = ntiles_k - 1;
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-        if (d < ntiles_k) load_tile(d, ra[d], rb[d], rmask[d]);
-    store_tile(0, ra[0], rb[0], rmask[0], 0);
-    __syncthreads();
-    for (int kt0 = 0; kt0 < ntiles_k; kt0 += DEPTH) {
+        for (int d = 0; d < DEPTH; ++d) load_tile(min(d, last), ra[d], rb[d], rmask[d]);
+        store_tile(0, ra[0], rb[0], rmask[0], 0);
+        __syncthreads();
+        for (int kt0 = 0; kt0 < ntiles_k; kt0 += DEPTH) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const int kt = kt0 + d;
-            if (kt < ntiles_k) {
+            for (int d = 0; d < DEPTH; ++d) {
+                const int kt = kt0 + d;
                 // stage d held tile kt, already copied to LDS: refill it with tile kt+DEPTH (DEPTH loads stay in flight)
-                if (kt + DEPTH < ntiles_k) load_tile(kt + DEPTH, ra[d], rb[d], rmask[d]);
-                compute(kt & 1);
-                if (kt + 1 < ntiles_k) store_tile((kt + 1) & 1, ra[(d + 1) % DEPTH], rb[(d + 1) % DEPTH], rmask[(d + 1) % DEPTH], kt + 1);
+                load_tile(min(kt + DEPTH, last), ra[d], rb[d], rmask[d]);
+                if (kt < ntiles_k) compute(kt & 1);
+                store_tile((kt + 1) & 1, ra[(d + 1) % DEPTH], rb[(d + 1) % DEPTH], rmask[(d + 1) % DEPTH], min(kt + 1, last));
                 __syncthreads();
             }
         }
@@ -516,10 +520,11 @@ static void plan_tiles(ConvArgs& a, int BM, int BN) {
     a.total_tiles = t;
 }
 
-static size_t conv_smem_bytes(int BM, int BN, int KTOT, int norm_channels) {
+static size_t conv_smem_bytes(int BM, int BN, int KTOT, int plain, int norm_channels) {
     const int STAGE = 2 * (BM * 128 + BN * 128);
     const int CB = BM * (BN + 4) * 4;
-    return (size_t)(STAGE > CB ? STAGE : CB) + 2 * BN * 4 + (size_t)cdiv(KTOT, 64) * 8 * 4 + (size_t)BM * 4 + (size_t)norm_channels * 8;
+    return (size_t)(STAGE > CB ? STAGE : CB) + 2 * BN * 4 + (plain ? 0 : (size_t)cdiv(KTOT, 64) * 8 * 16) + (size_t)BM * 4 +
+           (size_t)norm_channels * 8;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN, bool NORM>
@@ -538,7 +543,7 @@ template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN, boo
 static int launch_conv_p(const ConvArgs& a0, hipStream_t st) {
     ConvArgs a = a0;
     plan_tiles(a, BM, BN);
-    const size_t smem = conv_smem_bytes(BM, BN, a.KTOT, NORM ? a.CS : 0);
+    const size_t smem = conv_smem_bytes(BM, BN, a.KTOT, PLAIN ? 1 : 0, NORM ? a.CS : 0);
     if (smem > 160 * 1024) {
         set_error("conv: K=%d needs %zu B of LDS (>160 KiB)", a.KTOT, smem);
         return FN_EUNSUPPORTED;
@@ -720,54 +725,50 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bx
     }
 
     u32x4 ra[DEPTH][AP], rb[DEPTH][BP];
-    unsigned bmask[DEPTH];   // NORM: which X chunks of a stage hold real pixels
+    unsigned bmask[DEPTH];   // bits 0.. = dY chunks, bits 8.. = X chunks that hold real data (loads are unconditional, see conv_igemm_body)
     auto load_tile = [&](int stg, u32x4 (&ra)[AP], u32x4 (&rb)[BP], unsigned& msk) {
-        msk = 0u;
+        unsigned mk = 0u;
         const int mb = mbeg + stg * BK;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int m = mb + arow[i];
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (m < mend && acol[i] < a.Cout) v = *reinterpret_cast<const u32x4*>(a.dy + (long)m * a.ld_y + acol[i]);
-            ra[i] = v;
+            const bool ok = m < mend && acol[i] < a.Cout;
+            const long off = ok ? (long)m * a.ld_y + acol[i] : 0L;
+            ra[i] = load_global_b128(a.dy, off);
+            mk |= (ok ? 1u : 0u) << i;
         }
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
             const int m = mb + brow[j];
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (m < mend && bcol_ok[j]) {
-                long pix;
-                bool ok = true;
-                if (a.plain) {
-                    pix = m;
-                } else {
-                    int n, rem, oy, ox;
-                    fast_divmod(m, a.OH * a.OW, a.inv_ohw, n, rem);
-                    fast_divmod(rem, a.OW, a.inv_ow, oy, ox);
-                    const int iy = oy * a.stride + bcol_dy[j], ix = ox * a.stride + bcol_dx[j];
-                    ok = (iy >= 0) && (ix >= 0) && (iy < a.H) && (ix < a.W);
-                    pix = (long)(n * a.H + iy) * a.W + ix;
-                }
-                if (ok) {
-                    v = *reinterpret_cast<const u32x4*>(a.x + pix * a.ld_x + bcol_c[j]);
-                    msk |= 1u << j;
-                }
+            bool ok = m < mend && bcol_ok[j];
+            long pix = m;
+            if (!a.plain) {
+                int n, rem, oy, ox;
+                fast_divmod(m, a.OH * a.OW, a.inv_ohw, n, rem);
+                fast_divmod(rem, a.OW, a.inv_ow, oy, ox);
+                const int iy = oy * a.stride + bcol_dy[j], ix = ox * a.stride + bcol_dx[j];
+                ok = ok && (iy >= 0) && (ix >= 0) && (iy < a.H) && (ix < a.W);
+                pix = (long)(n * a.H + iy) * a.W + ix;
             }
-            rb[j] = v;
+            const long off = ok ? pix * a.ld_x + bcol_c[j] : 0L;
+            rb[j] = load_global_b128(a.x, off);
+            mk |= (ok ? 1u : 0u) << (8 + j);
         }
+        msk = mk;
     };
     auto store_tile = [&](int buf, const u32x4 (&ra)[AP], const u32x4 (&rb)[BP], const unsigned msk) {
+        const u32x4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int cidx = tid + 256 * i;
-            *reinterpret_cast<u32x4*>(sA + buf * A_BYTES + arow[i] * RSA + (cidx % CGA) * 16) = ra[i];
+            *reinterpret_cast<u32x4*>(sA + buf * A_BYTES + arow[i] * RSA + (cidx % CGA) * 16) = (msk & (1u << i)) ? ra[i] : zero;
         }
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
             const int cidx = tid + 256 * j;
-            u32x4 v = rb[j];
+            u32x4 v = (msk & (1u << (8 + j))) ? rb[j] : zero;
             if constexpr (NORM) {
-                if (msk & (1u << j)) {
+                if (msk & (1u << (8 + j))) {
                     const int col = (cidx % CGB) * 8;
                     const f32x4 s0 = *reinterpret_cast<const f32x4*>(sNs + col), s1 = *reinterpret_cast<const f32x4*>(sNs + col + 4);
                     const f32x4 h0 = *reinterpret_cast<const f32x4*>(sNh + col), h1 = *reinterpret_cast<const f32x4*>(sNh + col + 4);
@@ -820,21 +821,19 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bx
         }
     };
 
+    const int last = nst - 1;   // branch-free steady state, clamped stage index (see conv_igemm_body)
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-        if (d < nst) load_tile(d, ra[d], rb[d], bmask[d]);
+    for (int d = 0; d < DEPTH; ++d) load_tile(min(d, last), ra[d], rb[d], bmask[d]);
     store_tile(0, ra[0], rb[0], bmask[0]);
     __syncthreads();
     for (int s0 = 0; s0 < nst; s0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const int stg = s0 + d;
-            if (stg < nst) {
-                if (stg + DEPTH < nst) load_tile(stg + DEPTH, ra[d], rb[d], bmask[d]);
-                compute(stg & 1);
-                if (stg + 1 < nst) store_tile((stg + 1) & 1, ra[(d + 1) % DEPTH], rb[(d + 1) % DEPTH], bmask[(d + 1) % DEPTH]);
-                __syncthreads();
-            }
+            load_tile(min(stg + DEPTH, last), ra[d], rb[d], bmask[d]);
+            if (stg < nst) compute(stg & 1);
+            store_tile((stg + 1) & 1, ra[(d + 1) % DEPTH], rb[(d + 1) % DEPTH], bmask[(d + 1) % DEPTH]);
+            __syncthreads();
         }
     }
 
@@ -970,6 +969,10 @@ static int make_fwd_args(const fn_conv_desc* d, ConvArgs& a) {
     a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0) ? 1 : 0;
     a.stats_replicas = d->stats_replicas > 0 ? d->stats_replicas : 1;
     a.stats_rep_stride = d->stats_rep_stride;
+    FN_REQUIRE((long)d->N * d->H * d->W * d->ld_x * 2 < (1L << 30) && (long)d->Cout * a.KTOT * 2 < (1L << 30),
+               "conv_fwd: x or w exceeds the 1 GiB range of 32-bit buffer offsets");
+    a.src_bytes = d->N * d->H * d->W * d->ld_x * 2;
+    a.w_bytes = d->Cout * a.KTOT * 2;
     if (d->nrm_stats) {
         FN_REQUIRE(d->nrm_beta && d->Cin <= 512 && d->nrm_count > 0 && d->nrm_eps > 0.f, "conv_fwd: normalise-on-load needs beta, Cin <= 512, count, eps");
         a.nrm_stats = d->nrm_stats; a.nrm_beta = d->nrm_beta; a.nrm_sq_off = d->nrm_sq_off;
@@ -995,6 +998,10 @@ static int make_dgrad_args(const fn_conv_desc* d, ConvArgs& a) {
     a.relu = 0; a.accumulate = d->accumulate; a.out_f32 = d->out_f32; a.scale = 1.f;
     a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0) ? 1 : 0;
     a.stats_replicas = 1;
+    FN_REQUIRE((long)d->N * d->OH * d->OW * d->ld_y * 2 < (1L << 30) && (long)d->Cin * a.KTOT * 2 < (1L << 30),
+               "conv_dgrad: dy or wt exceeds the 1 GiB range of 32-bit buffer offsets");
+    a.src_bytes = d->N * d->OH * d->OW * d->ld_y * 2;
+    a.w_bytes = d->Cin * a.KTOT * 2;
     if (d->bn_y) {
         FN_REQUIRE(!d->accumulate && !d->out_f32 && d->bn_scale && d->bn_shift && d->bn_beta && d->bn_acc && d->ld_bn_y % 8 == 0,
                    "conv_dgrad: fused BN reduction needs a sole-writer low-precision dx and all bn_* pointers");
@@ -1043,7 +1050,7 @@ extern "C" int fn_conv2d_group_build(const fn_conv_desc* descs, int n, int op, i
         plan_tiles(a, bm, bn);
         host_prefix[i] = (int32_t)total;
         total += (long)a.total_tiles;
-        const size_t sm = conv_smem_bytes(bm, bn, a.KTOT, a.nrm_stats ? a.CS : 0);
+        const size_t sm = conv_smem_bytes(bm, bn, a.KTOT, a.plain, a.nrm_stats ? a.CS : 0);
         if (sm > smem) smem = sm;
         out[i] = a;
     }
