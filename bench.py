@@ -97,7 +97,7 @@ def kernel_roofline(trainer, miner, lib, dump=None):
             tname = "__bf16" if descs[0].dtype == 0 else "_Float16"
             d0 = descs[0]
             plain = int(d0.KH == 1 and d0.KW == 1 and d0.stride == 1 and d0.pad_h == 0 and d0.pad_w == 0)
-            key = f"conv_igemm_grouped_kernel<{tname},{op.name.split(':')[1].replace('x', ',')},1x1={plain}>"
+            key = f"conv_igemm_grouped_kernel<{tname},{op.name.split(':')[1].replace('x', ',').replace('k', ',ks=')},1x1={plain}>"
             fl = sum(conv_flops(d, opi) for d in descs)
             g = groups.setdefault(key, dict(ms=0.0, flops=0.0, launches=0, bound="mfma"))
             g["flops"] += fl
@@ -121,7 +121,8 @@ def kernel_roofline(trainer, miner, lib, dump=None):
             if opi == 2:
                 key = f"conv_wgrad_kernel<{tname},{v // 1000},{v % 1000}>"
             else:
-                key = f"conv_igemm_kernel<{tname},{v // 1000},{v % 1000},1x1={plain}>"
+                ks = f",ks={v // 1000000}" if v >= 1000000 else ""
+                key = f"conv_igemm_kernel<{tname},{v % 1000000 // 1000},{v % 1000}{ks},1x1={plain}>"
             g = groups.setdefault(key, dict(ms=0.0, flops=0.0, launches=0, bound="mfma"))
             g["flops"] += conv_flops(d, opi)
             per_op.append(dict(op=op.name, kernel=key, us=round(ms * 1e3, 2), gflop=round(conv_flops(d, opi) / 1e9, 3),

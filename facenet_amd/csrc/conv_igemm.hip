@@ -66,26 +66,38 @@ struct ConvArgs {
     float nrm_eps;
 };
 
+// q = m / d, r = m % d through the hardware reciprocal (0 <= m < 2^24, d > 0): integer division is a ~40-instruction
+// sequence on this ISA and the prologue of every workgroup needs several
+__device__ __forceinline__ void rcp_divmod(int m, int d, int& q, int& r) { fast_divmod(m, d, __builtin_amdgcn_rcpf((float)d), q, r); }
+
 // class mode: taps ky in {qy, qy+2, ..}, kx in {qx, qx+2, ..}
 __device__ __forceinline__ int ktab_entry_s2(int kgroup, int CS, int KH, int KW, int qy, int qx) {
     const int nky = (KH - qy + 1) >> 1, nkx = (KW - qx + 1) >> 1;
     const int k = kgroup * 8;
     if (k >= nky * nkx * CS) return -1;
-    const int tap = k / CS, c = k - tap * CS;
-    const int ty = tap / nkx, tx = tap - ty * nkx;
+    int tap, c, ty, tx;
+    rcp_divmod(k, CS, tap, c);
+    rcp_divmod(tap, nkx, ty, tx);
     return ((qy + 2 * ty) << 24) | ((qx + 2 * tx) << 16) | c;
 }
 
 __device__ __forceinline__ int ktab_entry(int kgroup, int KTOT, int CS, int KW) {
     const int k = kgroup * 8;
     if (k >= KTOT) return -1;
-    const int tap = k / CS, c = k - tap * CS;
-    const int ky = tap / KW, kx = tap - ky * KW;
+    int tap, c, ky, kx;
+    rcp_divmod(k, CS, tap, c);
+    rcp_divmod(tap, KW, ky, kx);
     return (ky << 24) | (kx << 16) | c;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN, bool NORM>
+// KS > 1: in-launch split-K.  The workgroup has KS groups of 256 threads; group g multiplies k tiles g, g+KS, .. with its own
+// LDS staging buffers, the partial accumulators are summed through LDS into group 0, which runs the epilogue.  The layers
+// on the 17x17 / 8x8 / 3x3 maps have a few hundred workgroups and 9-36 k tiles each: their run time is the length of that
+// serial chain, and a CU has wave slots to spare.
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, bool NORM>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid) {
+    static_assert(KS == 1 || !NORM, "normalise-on-load is built for KS == 1 only");
+    constexpr int NT = 256 * KS;
     constexpr int BK = 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MREP = TM / 16, NREP = TN / 16;
@@ -94,17 +106,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     constexpr int STAGE_BYTES = 2 * (A_BYTES + B_BYTES);
     constexpr int CLD = BN + 4;
     constexpr int C_BYTES = BM * CLD * 4;
-    constexpr int MAIN_BYTES = STAGE_BYTES > C_BYTES ? STAGE_BYTES : C_BYTES;
+    constexpr int MAIN_BYTES = KS * STAGE_BYTES > C_BYTES ? KS * STAGE_BYTES : C_BYTES;
     typedef typename LP<T>::vec8 vec8;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sA = smem;
-    unsigned char* sB = smem + 2 * A_BYTES;
+    const int grp = KS == 1 ? 0 : (int)(threadIdx.x >> 8);   // split-K group of this thread
+    unsigned char* sA = smem + grp * STAGE_BYTES;
+    unsigned char* sB = sA + 2 * A_BYTES;
     float* sC = reinterpret_cast<float*>(smem);
     float* sRed = reinterpret_cast<float*>(smem + MAIN_BYTES);         // [2*BN]
     int4* sT = reinterpret_cast<int4*>(smem + MAIN_BYTES + 2 * BN * 4);  // tap table [ceil(KTOT/64)*8] (general convolutions)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, gtid = tid & 255, lane = tid & 63, wave = gtid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     int cls = 0, qy = 0, qx = 0, cls_M = a.M, ktot = a.KTOT, tm, tn, cny = 0, cnx = 0;
     if (!PLAIN && a.s2) {
@@ -116,16 +129,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         if (t >= a.cp2) { cls = 2; cp = a.cp2; cny = a.ny2; cnx = a.nx2; }
         if (t >= a.cp3) { cls = 3; cp = a.cp3; cny = a.ny3; cnx = a.nx3; }
         const int lt = t - cp;
-        tm = lt / a.tiles_n;
-        tn = lt - tm * a.tiles_n;
+        rcp_divmod(lt, a.tiles_n, tm, tn);
         qy = cls >> 1;
         qx = cls & 1;
         cls_M = (a.M / (a.PH * a.PW)) * cny * cnx;
         ktot = ((a.KH - qy + 1) >> 1) * ((a.KW - qx + 1) >> 1) * a.CS;
     } else {
         const int tile = xcd_remap(bid, a.tiles_m * a.tiles_n);
-        tm = tile / a.tiles_n;
-        tn = tile - tm * a.tiles_n;
+        rcp_divmod(tile, a.tiles_n, tm, tn);
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int ntiles_k = (ktot + BK - 1) / BK;
@@ -133,7 +144,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     float* sNs = reinterpret_cast<float*>(sRow + BM);   // NORM: [CS] scale, [CS] shift of the source channels
     float* sNh = sNs + a.CS;
     if constexpr (NORM) {
-        for (int c = tid; c < a.CS; c += 256) {
+        for (int c = tid; c < a.CS; c += NT) {
             float sc, sh, mean, var;
             bn_batch_affine(a.nrm_stats, c, a.nrm_sq_off, a.nrm_replicas, a.nrm_rep_stride, a.nrm_count, a.nrm_eps, a.nrm_beta[c], sc, sh,
                             mean, var);
@@ -154,7 +165,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.src), 0, a.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, a.w_bytes, 0x00020000);
     if constexpr (!PLAIN) {
-        for (int i = tid; i < ntiles_k * 8; i += 256) {
+        for (int i = tid; i < ntiles_k * 8; i += NT) {
             const int e = a.s2 ? ktab_entry_s2(i, a.CS, a.KH, a.KW, qy, qx) : ktab_entry(i, a.KTOT, a.CS, a.KW);
             int4 t = make_int4(0, (int)OOB, (int)OOB, 0);
             if (e >= 0) {
@@ -169,7 +180,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     }
     if (tid < 2 * BN) sRed[tid] = 0.f;
 
-    const int kg = tid & 7, r0 = tid >> 3;
+    const int kg = gtid & 7, r0 = gtid >> 3;
     int ry[AP], rx[AP];
     unsigned rbyte[AP], wbyte[BP];
 #pragma unroll
@@ -183,19 +194,21 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         } else if (a.s2) {
             if (m < cls_M) {
                 const int ny = cny, nx = cnx;
-                const int n = m / (ny * nx), rem = m - n * ny * nx;
-                const int j = rem / nx, ii = rem - j * nx;
+                int n, rem, j, ii;
+                rcp_divmod(m, ny * nx, n, rem);
+                rcp_divmod(rem, nx, j, ii);
                 const int py = 2 * j + ((qy - a.offy) & 1), px = 2 * ii + ((qx - a.offx) & 1);   // (py + pad) & 1 == qy
                 ry[i] = (py + a.offy - qy) >> 1;     // taps of the class sit at ry - (ky - qy)/2
                 rx[i] = (px + a.offx - qx) >> 1;
                 rbyte[i] = (unsigned)(((n * a.SH + ry[i]) * a.SW + rx[i]) * a.ld_src) * 2u;
-                if (kg == 0) sRow[r0 + 32 * i] = (n * a.PH + py) * a.PW + px;
-            } else if (kg == 0) {
+                if (kg == 0 && grp == 0) sRow[r0 + 32 * i] = (n * a.PH + py) * a.PW + px;
+            } else if (kg == 0 && grp == 0) {
                 sRow[r0 + 32 * i] = -1;
             }
         } else if (m < a.M) {
-            const int n = m / (a.PH * a.PW), rem = m - n * a.PH * a.PW;
-            const int py = rem / a.PW, px = rem - py * a.PW;
+            int n, rem, py, px;
+            rcp_divmod(m, a.PH * a.PW, n, rem);
+            rcp_divmod(rem, a.PW, py, px);
             ry[i] = py * a.so + a.offy;
             rx[i] = px * a.so + a.offx;
             rbyte[i] = (unsigned)(((n * a.SH + ry[i]) * a.SW + rx[i]) * a.ld_src) * 2u;
@@ -308,25 +321,47 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     // iterations only move data; nothing reads what they stage.
     if (ntiles_k > 0) {
         const int last = ntiles_k - 1;
+        const int n_iter = (ntiles_k + KS - 1) / KS;           // same trip count for every group (barriers are block-wide)
+        auto tile_of = [&](int it) { return grp + KS * it; };   // it-th k tile of this group
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) load_tile(min(d, last), ra[d], rb[d], rmask[d]);
-        store_tile(0, ra[0], rb[0], rmask[0], 0);
+        for (int d = 0; d < DEPTH; ++d) load_tile(min(tile_of(d), last), ra[d], rb[d], rmask[d]);
+        store_tile(0, ra[0], rb[0], rmask[0], min(tile_of(0), last));
         __syncthreads();
-        for (int kt0 = 0; kt0 < ntiles_k; kt0 += DEPTH) {
+        for (int it0 = 0; it0 < n_iter; it0 += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
-                const int kt = kt0 + d;
-                // stage d held tile kt, already copied to LDS: refill it with tile kt+DEPTH (DEPTH loads stay in flight)
-                load_tile(min(kt + DEPTH, last), ra[d], rb[d], rmask[d]);
-                if (kt < ntiles_k) compute(kt & 1);
-                store_tile((kt + 1) & 1, ra[(d + 1) % DEPTH], rb[(d + 1) % DEPTH], rmask[(d + 1) % DEPTH], min(kt + 1, last));
+                const int it = it0 + d;
+                // stage d held this group's tile `it`, already copied to LDS: refill it with tile it+DEPTH
+                load_tile(min(tile_of(it + DEPTH), last), ra[d], rb[d], rmask[d]);
+                if (tile_of(it) < ntiles_k) compute(it & 1);
+                store_tile((it + 1) & 1, ra[(d + 1) % DEPTH], rb[(d + 1) % DEPTH], rmask[(d + 1) % DEPTH], min(tile_of(it + 1), last));
                 __syncthreads();
             }
         }
     }
+    if constexpr (KS > 1) {   // partial accumulators of groups 1.. -> group 0 (same thread position, conflict-free b128 rows)
+        f32x4* sX = reinterpret_cast<f32x4*>(smem);
+        if (grp > 0) {
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) sX[((grp - 1) * MREP * NREP + i * NREP + j) * 256 + gtid] = acc[i][j];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int g = 1; g < KS; ++g)
+#pragma unroll
+                for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                    for (int j = 0; j < NREP; ++j) acc[i][j] += sX[((g - 1) * MREP * NREP + i * NREP + j) * 256 + gtid];
+        }
+        __syncthreads();
+    }
+    const bool active = grp == 0;   // group 0 owns the epilogue; the others only keep the barriers company
 
     // ---- epilogue -------------------------------------------------------------------------------
-    if (a.stats) {  // BatchNorm batch statistics from the fp32 accumulators (rows >= M are exact zeros)
+    if (a.stats && active) {  // BatchNorm batch statistics from the fp32 accumulators (rows >= M are exact zeros)
 #pragma unroll
         for (int j = 0; j < NREP; ++j) {
             float s = 0.f, q = 0.f;
@@ -348,13 +383,15 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             }
         }
     }
+    if (active) {
 #pragma unroll
-    for (int i = 0; i < MREP; ++i)
+        for (int i = 0; i < MREP; ++i)
 #pragma unroll
-        for (int j = 0; j < NREP; ++j)
+            for (int j = 0; j < NREP; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                sC[(wm * TM + i * 16 + fq * 4 + r) * CLD + wn * TN + j * 16 + fr] = acc[i][j][r];
+                for (int r = 0; r < 4; ++r)
+                    sC[(wm * TM + i * 16 + fq * 4 + r) * CLD + wn * TN + j * 16 + fr] = acc[i][j][r];
+    }
     __syncthreads();
 
     constexpr int CG = BN / 8, RP = 256 / CG;
@@ -363,7 +400,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     float bq1[8], bq2[8];   // fused BN-backward partial sums of this thread's 8 columns
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bq1[e] = 0.f; bq2[e] = 0.f; }
-    if (col < a.NOUT) {
+    if (active && col < a.NOUT) {
         float bnsc[8], bnsf[8], bnbt[8];
         if (a.bn_y) {
 #pragma unroll
@@ -452,10 +489,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     if (a.bn_y) {   // fold the RP row lanes through LDS (the C tile is no longer needed), one atomic per column per block
         __syncthreads();
         float* sP = reinterpret_cast<float*>(smem);   // [RP][2*BN]
+        if (active) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            sP[rr * 2 * BN + cg * 8 + e] = bq1[e];
-            sP[rr * 2 * BN + BN + cg * 8 + e] = bq2[e];
+            for (int e = 0; e < 8; ++e) {
+                sP[rr * 2 * BN + cg * 8 + e] = bq1[e];
+                sP[rr * 2 * BN + BN + cg * 8 + e] = bq2[e];
+            }
         }
         __syncthreads();
         if (tid < 2 * BN) {
@@ -477,21 +516,21 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN, bool NORM>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
-    conv_igemm_body<T, BM, BN, WM, WN, DEPTH, PLAIN, NORM>(a, blockIdx.x);
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, bool NORM>
+__global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(const ConvArgs a) {
+    conv_igemm_body<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, NORM>(a, blockIdx.x);
 }
 
 // Grouped form: one launch runs several INDEPENDENT convolutions of one tile variant (sibling inception towers, the
 // same dependency level of the launch list): args[g] is layer g, prefix[g] .. prefix[g+1] its workgroups.
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN, bool NORM>
-__global__ __launch_bounds__(256) void conv_igemm_grouped_kernel(const ConvArgs* __restrict__ args, const int* __restrict__ prefix, int n) {
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, bool NORM>
+__global__ __launch_bounds__(256 * KS) void conv_igemm_grouped_kernel(const ConvArgs* __restrict__ args, const int* __restrict__ prefix, int n) {
     const int bid = blockIdx.x;
     int g = 0;
     while (g + 1 < n && prefix[g + 1] <= bid) ++g;     // n is small (<= 8)
     g = __builtin_amdgcn_readfirstlane(g);             // provably wave-uniform: args[g] is fetched with scalar loads into SGPRs
     const ConvArgs a = args[g];
-    conv_igemm_body<T, BM, BN, WM, WN, DEPTH, PLAIN, NORM>(a, bid - prefix[g]);
+    conv_igemm_body<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, NORM>(a, bid - prefix[g]);
 }
 
 // tiles of a launch; in class mode (stride-2 dgrad) every parity class has its own row tiles
@@ -520,49 +559,51 @@ static void plan_tiles(ConvArgs& a, int BM, int BN) {
     a.total_tiles = t;
 }
 
-static size_t conv_smem_bytes(int BM, int BN, int KTOT, int plain, int norm_channels) {
-    const int STAGE = 2 * (BM * 128 + BN * 128);
+static size_t conv_smem_bytes(int BM, int BN, int KTOT, int plain, int norm_channels, int ks) {
+    const int STAGE = ks * 2 * (BM * 128 + BN * 128);
     const int CB = BM * (BN + 4) * 4;
     return (size_t)(STAGE > CB ? STAGE : CB) + 2 * BN * 4 + (plain ? 0 : (size_t)cdiv(KTOT, 64) * 8 * 16) + (size_t)BM * 4 +
            (size_t)norm_channels * 8;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN, bool NORM>
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, bool NORM>
 static int launch_conv_grouped_p(const ConvArgs* dev_args, const int32_t* dev_prefix, int n, int total, size_t smem, hipStream_t st) {
-    auto kern = conv_igemm_grouped_kernel<T, BM, BN, WM, WN, DEPTH, PLAIN, NORM>;
+    auto kern = conv_igemm_grouped_kernel<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, NORM>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(total), dim3(256), smem, st, dev_args, dev_prefix, n);
+    hipLaunchKernelGGL(kern, dim3(total), dim3(256 * KS), smem, st, dev_args, dev_prefix, n);
     return check_launch("conv_igemm_grouped");
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH, bool PLAIN, bool NORM>
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, bool NORM>
 static int launch_conv_p(const ConvArgs& a0, hipStream_t st) {
     ConvArgs a = a0;
     plan_tiles(a, BM, BN);
-    const size_t smem = conv_smem_bytes(BM, BN, a.KTOT, PLAIN ? 1 : 0, NORM ? a.CS : 0);
+    const size_t smem = conv_smem_bytes(BM, BN, a.KTOT, PLAIN ? 1 : 0, NORM ? a.CS : 0, KS);
     if (smem > 160 * 1024) {
         set_error("conv: K=%d needs %zu B of LDS (>160 KiB)", a.KTOT, smem);
         return FN_EUNSUPPORTED;
     }
-    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, DEPTH, PLAIN, NORM>;
+    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, NORM>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.total_tiles), dim3(256), smem, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.total_tiles), dim3(256 * KS), smem, st, a);
     return check_launch("conv_igemm");
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH>
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
-    if (a.nrm_stats)
-        return a.plain ? launch_conv_p<T, BM, BN, WM, WN, DEPTH, true, true>(a, st) : launch_conv_p<T, BM, BN, WM, WN, DEPTH, false, true>(a, st);
-    return a.plain ? launch_conv_p<T, BM, BN, WM, WN, DEPTH, true, false>(a, st) : launch_conv_p<T, BM, BN, WM, WN, DEPTH, false, false>(a, st);
+    if constexpr (KS == 1) {
+        if (a.nrm_stats)
+            return a.plain ? launch_conv_p<T, BM, BN, WM, WN, DEPTH, 1, true, true>(a, st) : launch_conv_p<T, BM, BN, WM, WN, DEPTH, 1, false, true>(a, st);
+    }
+    return a.plain ? launch_conv_p<T, BM, BN, WM, WN, DEPTH, KS, true, false>(a, st) : launch_conv_p<T, BM, BN, WM, WN, DEPTH, KS, false, false>(a, st);
 }
 
 // Tile choice.  BN: smallest padded width, ties -> larger tile.  BM: the largest of {128, 64, 32} that still gives
@@ -583,9 +624,29 @@ static void choose_conv_tile(int M, int NOUT, int& bm, int& bn) {
     while (bm == 32 && bn > 32 && (long)cdiv(M, 32) * cdiv(NOUT, bn) < minb) bn >>= 1;
 }
 
-// the nine tile variants: BM, BN, waves (M x N), register stages
-#define FN_CONV_VARIANTS(X) X(128, 128, 2, 2, 1) X(128, 64, 2, 2, 1) X(128, 32, 4, 1, 1) X(64, 128, 1, 4, 2) X(64, 64, 2, 2, 2) \
-    X(64, 32, 2, 2, 2) X(32, 128, 1, 4, 4) X(32, 64, 1, 4, 4) X(32, 32, 2, 2, 4)
+// In-launch split-K factor for the 32-row tiles: long k chains on few workgroups (see conv_igemm_body).
+static int choose_conv_ks(int M, int NOUT, int KTOT, int bm, int bn) {
+    static const int force = getenv("FN_CONV_KS") ? atoi(getenv("FN_CONV_KS")) : 0;   // tuning aid
+    if (bm != 32) return 1;
+    const long blocks = (long)cdiv(M, 32) * cdiv(NOUT, bn);
+    const int ntk = cdiv(KTOT, 64);
+    // measured (tools/dev_ksweep.py): the chain costs ~0.16 us per k tile only while a CU holds one workgroup; with 3+
+    // workgroups per CU the loop is issue-bound and splitting K just adds the reduction
+    int ks = 1;
+    if (ntk >= 8 && blocks <= 128) ks = 2;
+    if (ntk >= 16 && blocks <= 64 && bn <= 64) ks = 4;
+    if (force == 1) ks = 1;
+    if (force == 2 && ks > 2) ks = 2;
+    return ks;
+}
+
+// tile variants: BM, BN, waves (M x N), register stages, split-K groups
+#define FN_CONV_VARIANTS(X) X(128, 128, 2, 2, 1, 1) X(128, 64, 2, 2, 1, 1) X(128, 32, 4, 1, 1, 1) X(64, 128, 1, 4, 2, 1) X(64, 64, 2, 2, 2, 1) \
+    X(64, 32, 2, 2, 2, 1) X(32, 128, 1, 4, 4, 1) X(32, 64, 1, 4, 4, 1) X(32, 32, 2, 2, 4, 1)                                           \
+    X(32, 128, 1, 4, 4, 2) X(32, 64, 1, 4, 4, 2) X(32, 64, 1, 4, 4, 4) X(32, 32, 2, 2, 4, 2) X(32, 32, 2, 2, 4, 4)
+
+// variant code: BM*1000 + BN (+ KS*1000000 when KS > 1)
+static int variant_code(int bm, int bn, int ks) { return bm * 1000 + bn + (ks > 1 ? ks * 1000000 : 0); }
 
 template <typename T> static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     int bm, bn;
@@ -594,28 +655,33 @@ template <typename T> static int dispatch_conv(const ConvArgs& a, hipStream_t st
         int fm = 0, fnn = 0;
         if (sscanf(f, "%dx%d", &fm, &fnn) == 2) { bm = fm; bn = fnn; }
     }
-#define FN_X(BM_, BN_, WM_, WN_, D_) \
-    if (bm == BM_ && bn == BN_) return launch_conv<T, BM_, BN_, WM_, WN_, D_>(a, st);
+    const int ks = a.nrm_stats ? 1 : choose_conv_ks(a.M, a.NOUT, a.KTOT, bm, bn);
+#define FN_X(BM_, BN_, WM_, WN_, D_, KS_) \
+    if (bm == BM_ && bn == BN_ && ks == KS_) return launch_conv<T, BM_, BN_, WM_, WN_, D_, KS_>(a, st);
     FN_CONV_VARIANTS(FN_X)
 #undef FN_X
-    set_error("conv: no tile variant %dx%d", bm, bn);
+    set_error("conv: no tile variant %dx%d ks=%d", bm, bn, ks);
     return FN_EUNSUPPORTED;
 }
 
 template <typename T>
-static int dispatch_conv_grouped(const ConvArgs* dev_args, const int32_t* dev_prefix, int n, int total, int bm, int bn, int plain, size_t smem,
-                                 hipStream_t st) {
+static int dispatch_conv_grouped(const ConvArgs* dev_args, const int32_t* dev_prefix, int n, int total, int bm, int bn, int ks, int plain,
+                                 size_t smem, hipStream_t st) {
     const bool norm = (plain & 2) != 0;   // bit 1 of `plain`: every member normalises on load
     plain &= 1;
-#define FN_X(BM_, BN_, WM_, WN_, D_)                                                                                                  \
-    if (bm == BM_ && bn == BN_)                                                                                                       \
-        return norm ? (plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, true, true>(dev_args, dev_prefix, n, total, smem, st)    \
-                             : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, false, true>(dev_args, dev_prefix, n, total, smem, st))  \
-                    : (plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, true, false>(dev_args, dev_prefix, n, total, smem, st)   \
-                             : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, false, false>(dev_args, dev_prefix, n, total, smem, st));
+#define FN_X(BM_, BN_, WM_, WN_, D_, KS_)                                                                                                       \
+    if (bm == BM_ && bn == BN_ && ks == KS_) {                                                                                                  \
+        if constexpr (KS_ == 1) {                                                                                                               \
+            if (norm)                                                                                                                           \
+                return plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, 1, true, true>(dev_args, dev_prefix, n, total, smem, st)         \
+                             : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, 1, false, true>(dev_args, dev_prefix, n, total, smem, st);       \
+        }                                                                                                                                       \
+        return plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, KS_, true, false>(dev_args, dev_prefix, n, total, smem, st)              \
+                     : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, KS_, false, false>(dev_args, dev_prefix, n, total, smem, st);            \
+    }
     FN_CONV_VARIANTS(FN_X)
 #undef FN_X
-    set_error("conv_grouped: no tile variant %dx%d", bm, bn);
+    set_error("conv_grouped: no tile variant %dx%d ks=%d", bm, bn, ks);
     return FN_EUNSUPPORTED;
 }
 
@@ -1032,7 +1098,8 @@ extern "C" int fn_conv2d_arg_bytes(void) { return (int)sizeof(ConvArgs); }
 extern "C" int fn_conv2d_group_build(const fn_conv_desc* descs, int n, int op, int variant, void* host_args, int32_t* host_prefix,
                                      int32_t* smem_bytes) {
     FN_REQUIRE(descs && host_args && host_prefix && smem_bytes && n > 0 && (op == 0 || op == 1), "conv_group_build: bad arguments");
-    const int bm = variant / 1000, bn = variant % 1000;
+    const int ks = variant >= 1000000 ? variant / 1000000 : 1;
+    const int bm = variant % 1000000 / 1000, bn = variant % 1000;
     ConvArgs* out = reinterpret_cast<ConvArgs*>(host_args);
     long total = 0;
     size_t smem = 0;
@@ -1042,7 +1109,9 @@ extern "C" int fn_conv2d_group_build(const fn_conv_desc* descs, int n, int op, i
         if (int rc = (op == 0 ? make_fwd_args(&descs[i], a) : make_dgrad_args(&descs[i], a))) return rc;
         int m, k;
         choose_conv_tile(a.M, a.NOUT, m, k);
-        FN_REQUIRE(m == bm && k == bn, "conv_group_build: descriptor %d dispatches to %dx%d, group is %dx%d", i, m, k, bm, bn);
+        const int ksi = a.nrm_stats ? 1 : choose_conv_ks(a.M, a.NOUT, a.KTOT, m, k);
+        FN_REQUIRE(m == bm && k == bn && ksi == ks, "conv_group_build: descriptor %d dispatches to %dx%d ks=%d, group is %dx%d ks=%d", i, m, k,
+                   ksi, bm, bn, ks);
         FN_REQUIRE(descs[i].dtype == descs[0].dtype, "conv_group_build: mixed dtypes");
         const int pl = a.plain | (a.nrm_stats ? 2 : 0);
         if (plain0 < 0) plain0 = pl;
@@ -1050,7 +1119,7 @@ extern "C" int fn_conv2d_group_build(const fn_conv_desc* descs, int n, int op, i
         plan_tiles(a, bm, bn);
         host_prefix[i] = (int32_t)total;
         total += (long)a.total_tiles;
-        const size_t sm = conv_smem_bytes(bm, bn, a.KTOT, a.plain, a.nrm_stats ? a.CS : 0);
+        const size_t sm = conv_smem_bytes(bm, bn, a.KTOT, a.plain, a.nrm_stats ? a.CS : 0, ks);
         if (sm > smem) smem = sm;
         out[i] = a;
     }
@@ -1065,9 +1134,10 @@ extern "C" int fn_conv2d_grouped(const void* dev_args, const int32_t* dev_prefix
     FN_REQUIRE(dev_args && dev_prefix && n > 0 && n <= 64 && total_blocks > 0, "conv_grouped: bad arguments");
     FN_REQUIRE(dtype == FN_BF16 || dtype == FN_F16, "dtype %d unsupported", dtype);
     const ConvArgs* a = reinterpret_cast<const ConvArgs*>(dev_args);
+    const int ks = variant >= 1000000 ? variant / 1000000 : 1, bm = variant % 1000000 / 1000, bn = variant % 1000;
     return dtype == FN_BF16
-               ? dispatch_conv_grouped<__bf16>(a, dev_prefix, n, total_blocks, variant / 1000, variant % 1000, plain, (size_t)smem_bytes, (hipStream_t)stream)
-               : dispatch_conv_grouped<_Float16>(a, dev_prefix, n, total_blocks, variant / 1000, variant % 1000, plain, (size_t)smem_bytes, (hipStream_t)stream);
+               ? dispatch_conv_grouped<__bf16>(a, dev_prefix, n, total_blocks, bm, bn, ks, plain, (size_t)smem_bytes, (hipStream_t)stream)
+               : dispatch_conv_grouped<_Float16>(a, dev_prefix, n, total_blocks, bm, bn, ks, plain, (size_t)smem_bytes, (hipStream_t)stream);
 }
 
 static int make_wgrad_args(const fn_conv_desc* d, WgradArgs& a) {
@@ -1159,8 +1229,14 @@ extern "C" int fn_conv2d_wgrad_grouped(const void* dev_args, const int32_t* dev_
 extern "C" int fn_conv2d_variant(const fn_conv_desc* d, int op) {
     if (!d || op < 0 || op > 2) return FN_EINVAL;
     int a, b;
-    if (op == 0) choose_conv_tile(d->N * d->OH * d->OW, d->Cout, a, b);
-    else if (op == 1) choose_conv_tile(d->N * d->H * d->W, d->Cin, a, b);
-    else final_wgrad_tile(d->Cout, d->KH * d->KW * d->Cin, a, b);
+    if (op == 0) {
+        choose_conv_tile(d->N * d->OH * d->OW, d->Cout, a, b);
+        return variant_code(a, b, d->nrm_stats ? 1 : choose_conv_ks(d->N * d->OH * d->OW, d->Cout, d->KH * d->KW * d->Cin, a, b));
+    }
+    if (op == 1) {
+        choose_conv_tile(d->N * d->H * d->W, d->Cin, a, b);
+        return variant_code(a, b, choose_conv_ks(d->N * d->H * d->W, d->Cin, d->KH * d->KW * d->Cout, a, b));
+    }
+    final_wgrad_tile(d->Cout, d->KH * d->KW * d->Cin, a, b);
     return a * 1000 + b;
 }

@@ -119,7 +119,8 @@ def group_convs(ops: List[Op], net: Network) -> List[Op]:
                 reads.extend(ops[i].reads)
                 writes.extend(ops[i].writes)
             kname = "conv_fwd_grouped" if opi == 0 else "conv_dgrad_grouped"
-            fused_at[chunk[0]] = Op(f"{kname}:{variant // 1000}x{variant % 1000}:" + "+".join(ops[i].name.split(":", 1)[1] for i in chunk),
+            vname = f"{variant % 1000000 // 1000}x{variant % 1000}" + (f"k{variant // 1000000}" if variant >= 1000000 else "")
+            fused_at[chunk[0]] = Op(f"{kname}:{vname}:" + "+".join(ops[i].name.split(":", 1)[1] for i in chunk),
                                    lib.fn_conv2d_grouped, (_ptr(dev_args), _ptr(dev_prefix), n, total, variant, plain, smem.value, dt),
                                    keep=(descs, dev_args, dev_prefix, [ops[i] for i in chunk]), reads=tuple(reads), writes=tuple(writes))
             skip.update(chunk[1:])

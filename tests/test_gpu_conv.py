@@ -271,7 +271,8 @@ def test_conv_normalise_on_load_equals_materialised_bn(lib, case, dt):
         _lib.check(lib.fn_conv2d_wgrad(C.byref(d), stream()))
         torch.cuda.synchronize()
         outs.append((y, dw))
-    assert torch.equal(outs[0][0], outs[1][0])
+    # operands are bit-identical; the plain launch may use in-launch split-K (another summation order), the nrm one never does
+    assert rel_err(outs[1][0], outs[0][0]) < (2e-3 if dt == _lib.FN_BF16 else 3e-4)
     assert torch.equal(outs[0][1], outs[1][1])
     assert float(outs[0][0].float().abs().max()) > 0 and float(outs[0][1].abs().max()) > 0
     # fn_bn_finalize publishes the same scale / shift and moving statistics as the materialising kernel
