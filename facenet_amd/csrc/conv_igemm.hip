@@ -715,6 +715,7 @@ struct WgradArgs {
     int gx, gy, splits;  // grid of this layer inside a grouped launch
     int plain;  // 1x1 stride-1: source pixel == output pixel
     float inv_ow, inv_ohw;
+    int x_bytes, dy_bytes;   // extents for the buffer resource descriptors (< 2^30)
     // normalise-on-load of x (see fn_conv_desc.nrm_*)
     const float* nrm_stats;
     const float* nrm_beta;
@@ -791,48 +792,52 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bx
     }
 
     u32x4 ra[DEPTH][AP], rb[DEPTH][BP];
-    unsigned bmask[DEPTH];   // bits 0.. = dY chunks, bits 8.. = X chunks that hold real data (loads are unconditional, see conv_igemm_body)
+    unsigned bmask[DEPTH];   // NORM only: X chunks of a stage that hold real pixels (bits 8..)
+    // buffer loads with hardware zero fill (see conv_igemm_body): ragged rows / columns and padding need no select
+    constexpr unsigned OOB = 0x60000000u;
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.dy), 0, a.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, a.x_bytes, 0x00020000);
+    unsigned acolb[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) acolb[i] = acol[i] < a.Cout ? (unsigned)acol[i] * 2u : OOB;
     auto load_tile = [&](int stg, u32x4 (&ra)[AP], u32x4 (&rb)[BP], unsigned& msk) {
         unsigned mk = 0u;
         const int mb = mbeg + stg * BK;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int m = mb + arow[i];
-            const bool ok = m < mend && acol[i] < a.Cout;
-            const long off = ok ? (long)m * a.ld_y + acol[i] : 0L;
-            ra[i] = load_global_b128(a.dy, off);
-            mk |= (ok ? 1u : 0u) << i;
+            const unsigned off = m < mend ? (unsigned)m * (unsigned)a.ld_y * 2u + acolb[i] : OOB;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)off, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
             const int m = mb + brow[j];
             bool ok = m < mend && bcol_ok[j];
-            long pix = m;
+            int pix = m;
             if (!a.plain) {
                 int n, rem, oy, ox;
                 fast_divmod(m, a.OH * a.OW, a.inv_ohw, n, rem);
                 fast_divmod(rem, a.OW, a.inv_ow, oy, ox);
                 const int iy = oy * a.stride + bcol_dy[j], ix = ox * a.stride + bcol_dx[j];
-                ok = ok && (iy >= 0) && (ix >= 0) && (iy < a.H) && (ix < a.W);
-                pix = (long)(n * a.H + iy) * a.W + ix;
+                ok = ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                pix = (n * a.H + iy) * a.W + ix;
             }
-            const long off = ok ? pix * a.ld_x + bcol_c[j] : 0L;
-            rb[j] = load_global_b128(a.x, off);
-            mk |= (ok ? 1u : 0u) << (8 + j);
+            const unsigned off = ok ? ((unsigned)pix * (unsigned)a.ld_x + (unsigned)bcol_c[j]) * 2u : OOB;
+            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0);
+            if constexpr (NORM) mk |= (ok ? 1u : 0u) << (8 + j);
         }
         msk = mk;
     };
     auto store_tile = [&](int buf, const u32x4 (&ra)[AP], const u32x4 (&rb)[BP], const unsigned msk) {
-        const u32x4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int cidx = tid + 256 * i;
-            *reinterpret_cast<u32x4*>(sA + buf * A_BYTES + arow[i] * RSA + (cidx % CGA) * 16) = (msk & (1u << i)) ? ra[i] : zero;
+            *reinterpret_cast<u32x4*>(sA + buf * A_BYTES + arow[i] * RSA + (cidx % CGA) * 16) = ra[i];
         }
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
             const int cidx = tid + 256 * j;
-            u32x4 v = (msk & (1u << (8 + j))) ? rb[j] : zero;
+            u32x4 v = rb[j];
             if constexpr (NORM) {
                 if (msk & (1u << (8 + j))) {
                     const int col = (cidx % CGB) * 8;
@@ -1152,6 +1157,10 @@ static int make_wgrad_args(const fn_conv_desc* d, WgradArgs& a) {
     a.ld_x = d->ld_x; a.ld_y = d->ld_y;
     a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0) ? 1 : 0;
     a.inv_ow = 1.0f / (float)d->OW; a.inv_ohw = 1.0f / (float)(d->OH * d->OW);
+    FN_REQUIRE((long)d->N * d->H * d->W * d->ld_x * 2 < (1L << 30) && (long)a.M * d->ld_y * 2 < (1L << 30),
+               "conv_wgrad: x or dy exceeds the 1 GiB range of 32-bit buffer offsets");
+    a.x_bytes = d->N * d->H * d->W * d->ld_x * 2;
+    a.dy_bytes = a.M * d->ld_y * 2;
     if (d->nrm_stats) {
         FN_REQUIRE(d->nrm_beta && d->nrm_count > 0 && d->nrm_eps > 0.f, "conv_wgrad: normalise-on-load needs beta, count, eps");
         a.nrm_stats = d->nrm_stats; a.nrm_beta = d->nrm_beta; a.nrm_sq_off = d->nrm_sq_off;
