@@ -59,20 +59,33 @@ def time_ops_individually(ops, stream, lib, reps=3):
     return times
 
 
+def _mangle_hint(demangled):
+    """rocprofv3 reports demangled names: rebuild the template-argument part in mangled spelling for one matcher."""
+    import re
+    m = re.match(r"void fn::(\w+)<(__bf16|_Float16), (.*)>\(", demangled)
+    if not m:
+        return ""
+    args = "".join((f"Lb{int(a == 'true')}E" if a in ("true", "false") else f"Li{a}E") for a in m.group(3).split(", "))
+    return f"{m.group(1)}I{'DF16b' if m.group(2) == '__bf16' else 'DF16_'}{args}E"
+
+
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of one conv instantiation from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
     profiles/r01_pmc_hbm_traffic.json); None when the profile is absent."""
     import re
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
     m = re.match(r"(conv_igemm_kernel|conv_igemm_grouped_kernel|conv_wgrad_kernel|conv_wgrad_grouped_kernel)"
-                 r"<(__bf16|_Float16),(\d+),(\d+)(?:,1x1=(\d))?>", kernel_key)
+                 r"<(__bf16|_Float16),(\d+),(\d+)(?:,ks=(\d))?(?:,1x1=(\d))?>", kernel_key)
     if not (m and os.path.exists(path)):
         return None
-    pat = f"{m.group(1)}I{'DF16b' if m.group(2) == '__bf16' else 'DF16_'}Li{m.group(3)}ELi{m.group(4)}E"
-    tail = f"Lb{m.group(5)}E" if m.group(5) is not None else ""
+    tname = "DF16b" if m.group(2) == "__bf16" else "DF16_"
+    if "wgrad" in m.group(1):      # <T, BMW, BNW, NORM>
+        pat = re.compile(rf"{m.group(1)}I{tname}Li{m.group(3)}ELi{m.group(4)}ELb0EE")
+    else:                          # <T, BM, BN, WM, WN, DEPTH, KS, PLAIN, NORM>
+        pat = re.compile(rf"{m.group(1)}I{tname}Li{m.group(3)}ELi{m.group(4)}ELi\d+ELi\d+ELi\d+ELi{m.group(5) or 1}ELb{m.group(6)}ELb0EE")
     n = tot = 0.0
     for name, v in json.load(open(path))["kernels"].items():
-        if pat in name and tail in name:
+        if pat.search(name) or pat.search(_mangle_hint(name)):
             n += v["launches"]
             tot += v["launches"] * v["hbm_bytes_per_launch"]
     return round(tot / n) if n else None

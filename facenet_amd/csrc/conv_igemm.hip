@@ -941,8 +941,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_grouped_kernel(const WgradArgs
     }
     lo = __builtin_amdgcn_readfirstlane(lo);           // wave-uniform: scalar loads of args[lo]
     const WgradArgs a = args[lo];
-    const int local = bid - prefix[lo];
+    // Workgroups that share a pixel chunk (same split, all gx*gy tiles) are consecutive in the layer's logical order: inside
+    // the layer give every XCD a contiguous run of it, so a chunk of X / dY is fetched into one L2 instead of all eight
+    // (per layer, not per launch: whole layers on one XCD would unbalance the chip).
     const int gxy = a.gx * a.gy;
+    const int local = xcd_remap(bid - prefix[lo], gxy * a.splits);
     const int bz = local / gxy, r = local - bz * gxy;
     conv_wgrad_body<T, BMW, BNW, NORM>(a, r % a.gx, r / a.gx, bz);
 }
