@@ -45,12 +45,20 @@ class InceptionResnetV1:
             self._plans[key] = self.network.plan(n, training=training)
         return self._plans[key]
 
+    MAX_PLAN_BATCH = 256
+
     def __call__(self, inputs, training: bool = False, **kwargs) -> torch.Tensor:
         net = self.network
         x = torch.as_tensor(np.asarray(inputs)) if not torch.is_tensor(inputs) else inputs
         if x.dim() != 4 or x.shape[3] != 3:
             raise ValueError(f"expected NHWC images [N,{net.image_size},{net.image_size},3], got {tuple(x.shape)}")
         n = x.shape[0]
+        if not training and n > self.MAX_PLAN_BATCH:
+            # the kernels address an activation tensor with 32-bit byte offsets (< 1 GiB: 388 images at the 147x147x64 stem
+            # layer); inference has no cross-image coupling (BatchNorm folded), so larger batches run in slices
+            return torch.cat([self(x[i:i + self.MAX_PLAN_BATCH], training=False) for i in range(0, n, self.MAX_PLAN_BATCH)])
+        if training and n > 380:
+            raise ValueError(f"training batch {n} exceeds the 380 images one plan can address (per-GPU batch; use data parallelism)")
         if x.shape[1] != net.image_size or x.shape[2] != net.image_size:     # tf.image.resize, facenet.py:70
             src = x.to(net.device).contiguous()
             if src.dtype not in (torch.uint8, torch.float32):
