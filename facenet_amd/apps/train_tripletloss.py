@@ -60,7 +60,16 @@ def train_tripletloss(cfg, people_per_batch: int = 45, images_per_person: int = 
 @click.command()
 @click.option("--config", default=None, type=Path, help="Path to yaml config file with used options of the application.")
 def main(**options):
-    train_tripletloss(config_mod.load_config(options["config"]))
+    cfg = config_mod.load_config(options["config"])
+    if cfg.dataset.path:      # P x K batches from disk: the reference's equal-batches sampler (dataset.py:46-101), 20 classes x 5 images
+        from facenet_amd import dataset
+        loader = dataset.ImageLoader(config=cfg.image)
+        dbase = dataset.Database(cfg.dataset)
+        pipe = dataset.pipeline_with_equal_batches(loader, dbase.classes, cfg, processes=True)
+        train_tripletloss(cfg, people_per_batch=cfg.nrof_classes_per_batch, images_per_person=cfg.nrof_examples_per_class,
+                          pools=(images for images, _ in pipe))
+    else:
+        train_tripletloss(cfg)
 
 
 if __name__ == "__main__":
