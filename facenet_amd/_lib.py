@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
         ("ld_bn_y", C.c_int32), ("bn_sq_off", C.c_int32), ("bn_replicas", C.c_int32), ("bn_rep_stride", C.c_int32), ("bn_relu", C.c_int32),
         ("nrm_stats", C.c_void_p), ("nrm_beta", C.c_void_p),
         ("nrm_sq_off", C.c_int32), ("nrm_replicas", C.c_int32), ("nrm_rep_stride", C.c_int32), ("nrm_count", C.c_int32),
-        ("nrm_eps", C.c_float),
+        ("nrm_eps", C.c_float), ("tile_fwd", C.c_int32), ("tile_dgrad", C.c_int32),
     ]
 
 

@@ -59,6 +59,7 @@ struct ConvArgs {
     int ny0, ny1, ny2, ny3, nx0, nx1, nx2, nx3;   // pixels per image row / column of every class (scalars: no indexing)
     int total_tiles;
     int src_bytes, w_bytes;   // extents for the buffer resource descriptors (< 2^30)
+    int tile;                 // 0 = heuristic, BM*1000+BN = caller's choice (fn_conv_desc.tile_fwd / tile_dgrad)
     // normalise-on-load (forward only): src is the raw output of a BN(center)+ReLU layer, see fn_conv_desc.nrm_*
     const float* nrm_stats;
     const float* nrm_beta;
@@ -608,7 +609,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
 
 // Tile choice.  BN: smallest padded width, ties -> larger tile.  BM: the largest of {128, 64, 32} that still gives
 // >= 2 workgroups per CU (these launches are latency-bound: occupancy first), else the smallest (most workgroups).
-static void choose_conv_tile(int M, int NOUT, int& bm, int& bn) {
+static void choose_conv_tile_auto(int M, int NOUT, int& bm, int& bn) {
     bn = 128;
     long best = (long)cdiv(NOUT, 128) * 128;
     for (int c : {64, 32}) {
@@ -622,6 +623,17 @@ static void choose_conv_tile(int M, int NOUT, int& bm, int& bn) {
     }
     // narrow the N tile as well when even 32-row tiles leave most CUs idle
     while (bm == 32 && bn > 32 && (long)cdiv(M, 32) * cdiv(NOUT, bn) < minb) bn >>= 1;
+}
+
+static void choose_conv_tile(int M, int NOUT, int forced, int& bm, int& bn) {
+    if (forced > 0) { bm = forced / 1000; bn = forced % 1000; return; }   // validated by check_tile
+    choose_conv_tile_auto(M, NOUT, bm, bn);
+}
+
+static bool valid_tile(int t) {
+    if (t == 0) return true;
+    const int bm = t / 1000, bn = t % 1000;
+    return (bm == 128 || bm == 64 || bm == 32) && (bn == 128 || bn == 64 || bn == 32);
 }
 
 // In-launch split-K factor for the 32-row tiles: long k chains on few workgroups (see conv_igemm_body).
@@ -650,7 +662,7 @@ static int variant_code(int bm, int bn, int ks) { return bm * 1000 + bn + (ks > 
 
 template <typename T> static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     int bm, bn;
-    choose_conv_tile(a.M, a.NOUT, bm, bn);
+    choose_conv_tile(a.M, a.NOUT, a.tile, bm, bn);
     if (const char* f = getenv("FN_CONV_TILE")) {   // tuning aid: "BMxBN"
         int fm = 0, fnn = 0;
         if (sscanf(f, "%dx%d", &fm, &fnn) == 2) { bm = fm; bn = fnn; }
@@ -1047,6 +1059,8 @@ static int make_fwd_args(const fn_conv_desc* d, ConvArgs& a) {
                "conv_fwd: x or w exceeds the 1 GiB range of 32-bit buffer offsets");
     a.src_bytes = d->N * d->H * d->W * d->ld_x * 2;
     a.w_bytes = d->Cout * a.KTOT * 2;
+    FN_REQUIRE(valid_tile(d->tile_fwd), "conv_fwd: tile_fwd=%d is not one of {128,64,32}x{128,64,32}", d->tile_fwd);
+    a.tile = d->tile_fwd;
     if (d->nrm_stats) {
         FN_REQUIRE(d->nrm_beta && d->Cin <= 512 && d->nrm_count > 0 && d->nrm_eps > 0.f, "conv_fwd: normalise-on-load needs beta, Cin <= 512, count, eps");
         a.nrm_stats = d->nrm_stats; a.nrm_beta = d->nrm_beta; a.nrm_sq_off = d->nrm_sq_off;
@@ -1076,6 +1090,8 @@ static int make_dgrad_args(const fn_conv_desc* d, ConvArgs& a) {
                "conv_dgrad: dy or wt exceeds the 1 GiB range of 32-bit buffer offsets");
     a.src_bytes = d->N * d->OH * d->OW * d->ld_y * 2;
     a.w_bytes = d->Cin * a.KTOT * 2;
+    FN_REQUIRE(valid_tile(d->tile_dgrad), "conv_dgrad: tile_dgrad=%d is not one of {128,64,32}x{128,64,32}", d->tile_dgrad);
+    a.tile = d->tile_dgrad;
     if (d->bn_y) {
         FN_REQUIRE(!d->accumulate && !d->out_f32 && d->bn_scale && d->bn_shift && d->bn_beta && d->bn_acc && d->ld_bn_y % 8 == 0,
                    "conv_dgrad: fused BN reduction needs a sole-writer low-precision dx and all bn_* pointers");
@@ -1116,7 +1132,7 @@ extern "C" int fn_conv2d_group_build(const fn_conv_desc* descs, int n, int op, i
         ConvArgs a;
         if (int rc = (op == 0 ? make_fwd_args(&descs[i], a) : make_dgrad_args(&descs[i], a))) return rc;
         int m, k;
-        choose_conv_tile(a.M, a.NOUT, m, k);
+        choose_conv_tile(a.M, a.NOUT, a.tile, m, k);
         const int ksi = a.nrm_stats ? 1 : choose_conv_ks(a.M, a.NOUT, a.KTOT, m, k);
         FN_REQUIRE(m == bm && k == bn && ksi == ks, "conv_group_build: descriptor %d dispatches to %dx%d ks=%d, group is %dx%d ks=%d", i, m, k,
                    ksi, bm, bn, ks);
@@ -1242,11 +1258,11 @@ extern "C" int fn_conv2d_variant(const fn_conv_desc* d, int op) {
     if (!d || op < 0 || op > 2) return FN_EINVAL;
     int a, b;
     if (op == 0) {
-        choose_conv_tile(d->N * d->OH * d->OW, d->Cout, a, b);
+        choose_conv_tile(d->N * d->OH * d->OW, d->Cout, valid_tile(d->tile_fwd) ? d->tile_fwd : 0, a, b);
         return variant_code(a, b, d->nrm_stats ? 1 : choose_conv_ks(d->N * d->OH * d->OW, d->Cout, d->KH * d->KW * d->Cin, a, b));
     }
     if (op == 1) {
-        choose_conv_tile(d->N * d->H * d->W, d->Cin, a, b);
+        choose_conv_tile(d->N * d->H * d->W, d->Cin, valid_tile(d->tile_dgrad) ? d->tile_dgrad : 0, a, b);
         return variant_code(a, b, choose_conv_ks(d->N * d->H * d->W, d->Cin, d->KH * d->KW * d->Cout, a, b));
     }
     final_wgrad_tile(d->Cout, d->KH * d->KW * d->Cin, a, b);

@@ -14,7 +14,8 @@
 from __future__ import annotations
 
 import ctypes as C
-from typing import Callable, List, Optional, Sequence, Tuple
+import os
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -77,6 +78,56 @@ def group_wgrads(ops: List[Op], net: Network) -> List[Op]:
                       (_ptr(dev_args), _ptr(dev_prefix), n, total, variant, dt), keep=(descs, dev_args, dev_prefix, members),
                       reads=tuple(reads), writes=tuple(writes)))
     return out
+
+
+TILE_CANDIDATES = tuple((bm, bn) for bm in (128, 64, 32) for bn in (128, 64, 32))
+
+
+def autotune_convs(ops: Sequence[Op], net: Network, launches: int = 8, rounds: int = 2) -> Dict[str, int]:
+    """Measure, don't guess: time every forward / data-gradient convolution of a plan with each tile variant (a burst of
+    back-to-back launches between two HIP events, best of `rounds`) and write the winner into the descriptor
+    (fn_conv_desc.tile_fwd / tile_dgrad).  The library heuristic stays the fallback (FACENET_AUTOTUNE=0) and the tie
+    breaker: a candidate must beat it by 3 % to replace it.  Runs once per plan, before grouping and graph capture; what
+    the launches write while being timed is overwritten or re-zeroed by the first real step."""
+    if os.environ.get("FACENET_AUTOTUNE", "1") == "0":
+        return {}
+    lib, st = net.lib, net.stream()
+    chosen: Dict[str, int] = {}
+
+    def burst(op):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(launches):
+            rc = op.fn(*op.args, st)
+            if rc:
+                return float("inf")
+        b.record()
+        b.synchronize()
+        return a.elapsed_time(b)
+
+    for op in ops:
+        kind = op.name.split(":")[0]
+        if kind not in ("conv_fwd", "conv_dgrad") or not op.keep or not isinstance(op.keep[0], _lib.ConvDesc):
+            continue
+        d = op.keep[0]
+        field = "tile_fwd" if kind == "conv_fwd" else "tile_dgrad"
+        nout = d.Cout if kind == "conv_fwd" else d.Cin
+        setattr(d, field, 0)
+        base = lib.fn_conv2d_variant(C.byref(d), 0 if kind == "conv_fwd" else 1) % 1000000
+        timings = {}
+        for bm, bn in TILE_CANDIDATES:
+            if bn > 32 and bn // 2 >= nout:              # a tile twice as wide as the layer only multiplies zeros
+                continue
+            setattr(d, field, bm * 1000 + bn)
+            burst(op)                                    # warm-up (code object, L2)
+            timings[bm * 1000 + bn] = min(burst(op) for _ in range(rounds))
+        best = min(timings, key=timings.get)
+        if base in timings and timings[best] > 0.97 * timings[base]:
+            best = base
+        setattr(d, field, best)
+        chosen[op.name] = best
+    torch.cuda.synchronize()
+    return chosen
 
 
 def group_convs(ops: List[Op], net: Network) -> List[Op]:
@@ -227,6 +278,7 @@ class Trainer:
         self.buckets = self._make_buckets(n_buckets) if world_size > 1 else []
         self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
         self.streams = _streams_for(net, n_streams)
+        self.tiles = autotune_convs(self.plan.fwd + self.loss_ops + self.plan.bwd, net)
         self._build_segments()
         self._graph = None
 
@@ -383,6 +435,8 @@ class TripletMiner:
         bytes_per = train_images[0].numel()
         o.append(Op("fold_bn", lambda st: (net.refresh_folded(st), 0)[1], (),
                     reads=(region(net.P), region(net.S_mean), region(net.S_var)), writes=(region(net.W_infer), region(net.fold_bias))))
+        net.refresh_folded(net.stream())          # the inference pack must exist before launches are timed
+        self.tiles = autotune_convs(self.plan.fwd, net)
         o.extend(self.plan.fwd)
         o.append(Op("l2norm_fwd", lib.fn_l2norm_fwd, (_ptr(self.emb), _ptr(self.embn), n, E, 1e-10),
                     reads=(region(self.plan.embedding.buf.act),), writes=(region(self.embn),)))

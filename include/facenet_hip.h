@@ -74,6 +74,10 @@ typedef struct fn_conv_desc {
     const float* nrm_beta;
     int32_t nrm_sq_off, nrm_replicas, nrm_rep_stride, nrm_count;
     float nrm_eps;
+    /* fwd / dgrad tile variant: 0 = library heuristic, BM*1000+BN with BM, BN in {128, 64, 32} = caller's choice (the host side
+     * times the candidates once per plan: facenet_amd/engine.py autotune).  Results do not depend on the tile beyond the
+     * summation order. */
+    int32_t tile_fwd, tile_dgrad;
 } fn_conv_desc;
 
 int fn_conv2d_fwd(const fn_conv_desc* d, void* stream);
