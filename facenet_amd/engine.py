@@ -301,6 +301,7 @@ class Network:
         self.P.copy_(P)
         self.S_mean.copy_(mean)
         self.S_var.copy_(var)
+        self.folded_valid = False
         self.refresh_packs()
 
     def export_keras_params(self) -> "OrderedDict[str, torch.Tensor]":
@@ -346,7 +347,13 @@ class Network:
         _lib.check(self.lib.fn_pack_transpose(_ptr(self.W_train), _ptr(self.Wt_train), _ptr(self.table), len(self.layers),
                                               self.max_layer_elems, _lib.dtype_code(self.train_dtype), st), "pack_transpose")
 
-    def refresh_folded(self, st: int):
+    def refresh_folded(self, st: int, force: bool = True):
+        """BN-folded inference pack from the fp32 masters.  `force=False` skips the launch while nothing has changed the
+        parameters or the moving statistics since the last fold (`folded_valid`; cleared by load_keras_params, by every
+        trainer step and by training-mode forwards)."""
+        if not force and getattr(self, "folded_valid", False):
+            return
+        self.folded_valid = True
         _lib.check(self.lib.fn_fold_bn(_ptr(self.P), _ptr(self.W_infer), _ptr(self.fold_bias), _ptr(self.P, self.beta_base),
                                        _ptr(self.S_mean), _ptr(self.S_var), _ptr(self.table), len(self.layers),
                                        self.max_layer_elems, BN_EPS, _lib.dtype_code(self.infer_dtype), st), "fold_bn")

@@ -34,6 +34,7 @@ class InceptionResnetV1:
                               "block8_2", "features")          # :470-480
         self._plans: Dict[tuple, Lowering] = {}
         self._f32_in: Dict[int, torch.Tensor] = {}
+        self._graphs: Dict[int, tuple] = {}      # inference: batch size -> (HIP graph of the plan + l2_normalize, output buffer)
 
     @property
     def embedding_size(self) -> int:
@@ -42,10 +43,17 @@ class InceptionResnetV1:
     def _plan(self, n: int, training: bool) -> Lowering:
         key = (n, training)
         if key not in self._plans:
-            self._plans[key] = self.network.plan(n, training=training)
+            plan = self.network.plan(n, training=training)
+            if n >= 16:     # batches worth the ~0.3 s: time the tile variants of every convolution once (train.autotune_convs)
+                from ..train import autotune_convs
+                if not training:
+                    self.network.refresh_folded(self.network.stream())
+                autotune_convs(plan.fwd, self.network)
+            self._plans[key] = plan
         return self._plans[key]
 
     MAX_PLAN_BATCH = 256
+    use_graphs = True       # inference calls on uint8 images replay a captured HIP graph per batch size
 
     def __call__(self, inputs, training: bool = False, **kwargs) -> torch.Tensor:
         net = self.network
@@ -68,8 +76,31 @@ class InceptionResnetV1:
                                                         net.image_size, net.image_size, net.stream()), "image_resize")
         plan = self._plan(n, training)
         st = net.stream()
-        if not training:
-            net.refresh_folded(st)
+        if training:
+            net.folded_valid = False       # the forward below updates the moving statistics
+        else:
+            net.refresh_folded(st, force=False)
+        if x.dtype == torch.uint8 and not training and self.use_graphs:
+            # serving path: the whole plan + l2_normalize replayed as ONE HIP graph (107 launches; at batch 1 the eager
+            # Python dispatch costs more than the kernels)
+            plan.images.copy_(x.to(net.device))
+            if n not in self._graphs:
+                out = torch.empty(n, net.E, dtype=torch.float32, device=net.device)
+                emb = plan.embedding.buf.act.view(n, net.E)
+
+                def run():
+                    s_ = net.stream()
+                    Lowering.run_ops(plan.fwd, s_)
+                    _lib.check(net.lib.fn_l2norm_fwd(_ptr(emb), _ptr(out), n, net.E, 1e-10, s_), "l2norm")
+                run()                                  # warm-up outside the capture
+                torch.cuda.synchronize(net.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    run()
+                self._graphs[n] = (g, out)
+            g, out = self._graphs[n]
+            g.replay()
+            return out.clone()
         if x.dtype == torch.uint8:
             plan.images.copy_(x.to(net.device))
             Lowering.run_ops(plan.fwd, st)

@@ -345,6 +345,7 @@ class Trainer:
         self.plan.ws_b.zero_()
 
     def _run_segments(self, launch: Callable[[int], None]):
+        self.net.folded_valid = False        # parameters and moving statistics are about to change
         if self.world == 1:
             launch(0)
             return
