@@ -14,6 +14,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import json
 import os
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -93,6 +94,14 @@ def autotune_convs(ops: Sequence[Op], net: Network, launches: int = 8, rounds: i
         return {}
     lib, st = net.lib, net.stream()
     chosen: Dict[str, int] = {}
+    # FACENET_TUNE_CACHE=<file>: reuse the tiles of an earlier run (same shapes) instead of timing again -- reproducible
+    # plans, and profiles of a tuned run that do not contain the tuning bursts
+    cache_path = os.environ.get("FACENET_TUNE_CACHE")
+    cache: Dict[str, int] = {}
+    if cache_path and os.path.exists(cache_path):
+        with open(cache_path) as fh:
+            cache = json.load(fh)
+    dirty = False
 
     def burst(op):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -112,6 +121,11 @@ def autotune_convs(ops: Sequence[Op], net: Network, launches: int = 8, rounds: i
         d = op.keep[0]
         field = "tile_fwd" if kind == "conv_fwd" else "tile_dgrad"
         nout = d.Cout if kind == "conv_fwd" else d.Cin
+        key = f"{op.name}|N{d.N}|{d.H}x{d.W}x{d.Cin}|dt{d.dtype}|nrm{int(bool(d.nrm_stats))}"
+        if key in cache:
+            setattr(d, field, int(cache[key]))
+            chosen[op.name] = int(cache[key])
+            continue
         setattr(d, field, 0)
         base = lib.fn_conv2d_variant(C.byref(d), 0 if kind == "conv_fwd" else 1) % 1000000
         timings = {}
@@ -126,7 +140,12 @@ def autotune_convs(ops: Sequence[Op], net: Network, launches: int = 8, rounds: i
             best = base
         setattr(d, field, best)
         chosen[op.name] = best
+        cache[key] = best
+        dirty = True
     torch.cuda.synchronize()
+    if cache_path and dirty:
+        with open(cache_path, "w") as fh:
+            json.dump(cache, fh, indent=0)
     return chosen
 
 

@@ -13,6 +13,16 @@ def main():
         for r, n in zip(rows, names):
             w.writerow([n, r[1], round(r[2], 3), round(r[3], 3), round(r[4], 3)])
     print(f"{len(rows)} kernels -> {out}")
+    if len(sys.argv) > 3:          # optional markdown summary of the top 30
+        total = sum(r[2] for r in rows)
+        with open(sys.argv[3], "w") as fh:
+            fh.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline   (MI355X, round 1, final state)\n")
+            fh.write("# the run = autotune bursts + warm-up + capture + 20 timed + 10 train-only graph replays + ONE eager per-launch timing pass;\n")
+            fh.write(f"# durations are per kernel launch.  Total kernel time {total / 1e3:.1f} ms.  Names are mangled: IDF16b = __bf16, IDF16_ = _Float16,\n")
+            fh.write("# conv_igemm template arguments = BM, BN, waves M, waves N, register stages, split-K groups, 1x1 fast path, normalise-on-load.\n\n")
+            fh.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+            for r in sorted(rows, key=lambda r: -r[2])[:30]:
+                fh.write(f"| `{r[0]}` | {r[1]} | {r[2] / 1e3:.2f} | {r[3]:.1f} | {r[4]:.2f} |\n")
 
 
 if __name__ == "__main__":
