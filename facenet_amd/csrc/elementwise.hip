@@ -139,6 +139,16 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* 
     const int lin_ = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);   // rows -> XCD like the convolutions
     const int bx_ = lin_ / gridDim.y, by_ = lin_ - bx_ * gridDim.y;
     const int c0 = by_ * 64;
+    // The first chunk of every thread is requested BEFORE the statistics prologue: most launches give a thread one or two
+    // 16-byte chunks, so the kernel is two dependent memory round trips (statistics, then data) unless they overlap.
+    const int ncg = min(8, (C - c0) >> 3);
+    const int TX = ncg <= 1 ? 1 : (ncg <= 2 ? 2 : (ncg <= 4 ? 4 : 8));   // narrow stripes keep all 256 threads busy
+    const int TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int r0 = bx_ * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const int c = c0 + tx * 8;
+    u32x4 pre = {0u, 0u, 0u, 0u};
+    if (tx < ncg && r0 + ty < r1) pre = *reinterpret_cast<const u32x4*>(y + (long)(r0 + ty) * ld_y + c);
     {   // replica sums: 4 thread groups x 64 channels, independent loads in flight (a rolled serial loop would expose
         // one memory latency per replica)
         const int cc = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -175,19 +185,13 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* 
         }
     }
     __syncthreads();
-    const int ncg = min(8, (C - c0) >> 3);
-    const int TX = ncg <= 1 ? 1 : (ncg <= 2 ? 2 : (ncg <= 4 ? 4 : 8));   // narrow stripes keep all 256 threads busy
-    const int TY = 256 / TX;
-    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     if (tx >= ncg) return;
     float sc[8], sf[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = s_scale[tx * 8 + e]; sf[e] = s_shift[tx * 8 + e]; }
-    const int r0 = bx_ * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    const int c = c0 + tx * 8;
     for (int r = r0 + ty; r < r1; r += TY) {
         float v[8];
-        unpack8<T>(*reinterpret_cast<const u32x4*>(y + (long)r * ld_y + c), v);
+        unpack8<T>(r == r0 + ty ? pre : *reinterpret_cast<const u32x4*>(y + (long)r * ld_y + c), v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float zf = fmaf(v[e], sc[e], sf[e]);
@@ -274,6 +278,18 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(unsigned short* 
     const int lin_ = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);   // rows -> XCD like the convolutions
     const int bx_ = lin_ / gridDim.y, by_ = lin_ - bx_ * gridDim.y;
     const int c0 = by_ * 64;
+    // first chunk of dz / y requested before the reduction prologue (see bn_relu_fwd_kernel)
+    const int ncg = min(8, (C - c0) >> 3);
+    const int TX = ncg <= 1 ? 1 : (ncg <= 2 ? 2 : (ncg <= 4 ? 4 : 8));
+    const int TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = c0 + tx * 8;
+    const int r0 = bx_ * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    u32x4 pre_g = {0u, 0u, 0u, 0u}, pre_y = {0u, 0u, 0u, 0u};
+    if (tx < ncg && r0 + ty < r1) {
+        pre_g = *reinterpret_cast<const u32x4*>(dz + (long)(r0 + ty) * ld_d + c);
+        pre_y = *reinterpret_cast<const u32x4*>(y + (long)(r0 + ty) * ld_y + c);
+    }
     {
         const int cc = threadIdx.x & 63, q = threadIdx.x >> 6;
         float s1 = 0.f, s2v = 0.f;
@@ -297,23 +313,18 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(unsigned short* 
         if (bx_ == 0) dbeta[c0 + threadIdx.x] += s1;
     }
     __syncthreads();
-    const int ncg = min(8, (C - c0) >> 3);
-    const int TX = ncg <= 1 ? 1 : (ncg <= 2 ? 2 : (ncg <= 4 ? 4 : 8));
-    const int TY = 256 / TX;
-    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     if (tx >= ncg) return;
-    const int c = c0 + tx * 8;
     float k1[8], k2[8], sc[8], sf[8], bt[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         k1[e] = s_k1[tx * 8 + e]; k2[e] = s_k2[tx * 8 + e]; sc[e] = scale[c + e]; sf[e] = shift[c + e]; bt[e] = beta[c + e];
     }
-    const int r0 = bx_ * rows_per_block, r1 = min(M, r0 + rows_per_block);
     for (int r = r0 + ty; r < r1; r += TY) {
         unsigned short* p = dz + (long)r * ld_d + c;
         float g[8], yy[8];
-        unpack8<T>(*reinterpret_cast<const u32x4*>(p), g);
-        unpack8<T>(*reinterpret_cast<const u32x4*>(y + (long)r * ld_y + c), yy);
+        const bool first = r == r0 + ty;
+        unpack8<T>(first ? pre_g : *reinterpret_cast<const u32x4*>(p), g);
+        unpack8<T>(first ? pre_y : *reinterpret_cast<const u32x4*>(y + (long)r * ld_y + c), yy);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float zf = fmaf(yy[e], sc[e], sf[e]);
