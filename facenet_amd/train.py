@@ -144,8 +144,10 @@ def autotune_convs(ops: Sequence[Op], net: Network, launches: int = 8, rounds: i
         dirty = True
     torch.cuda.synchronize()
     if cache_path and dirty:
-        with open(cache_path, "w") as fh:
+        tmp = f"{cache_path}.{os.getpid()}.tmp"        # several ranks may share the file: replace it atomically
+        with open(tmp, "w") as fh:
             json.dump(cache, fh, indent=0)
+        os.replace(tmp, cache_path)
     return chosen
 
 
