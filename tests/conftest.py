@@ -1,7 +1,12 @@
 import os
 import sys
 
+import os
+
 import pytest
+
+# plans in the tests use the library tile heuristic (deterministic, fast); the tuner has its own test
+os.environ.setdefault("FACENET_AUTOTUNE", "0")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -220,3 +220,32 @@ def test_normalise_on_load_plan_matches_materialised_plan(monkeypatch):
     print("noise floor (emb, grad):", floor, " normalise-on-load vs default:", d)
     assert d[0] <= 3 * floor[0] + 2e-3 and d[1] <= 3 * floor[1] + 2e-2
     assert torch.allclose(results[2][4], results[0][4], rtol=1e-3, atol=1e-4) and torch.allclose(results[2][5], results[0][5], rtol=1e-3, atol=1e-4)
+
+
+def test_autotuned_plan_matches_heuristic_plan(monkeypatch, tmp_path):
+    """train.autotune_convs times the nine tile variants of every forward / data-gradient convolution and pins the winner in
+    the descriptor; results may differ from the heuristic plan only by summation order.  The tile cache replays the choice."""
+    from tests.util import structured_images
+    E, N = 128, 6
+    params, _, _ = fo.build_params(E, seed=0)
+    x = torch.from_numpy(structured_images(N, seed=7))
+    cache = tmp_path / "tiles.json"
+    results, tiles = [], []
+    for mode in ("0", "0", "1", "cached"):
+        monkeypatch.setenv("FACENET_AUTOTUNE", "0" if mode == "0" else "1")
+        if mode != "0":
+            monkeypatch.setenv("FACENET_TUNE_CACHE", str(cache))
+        net = Network(embedding_size=E, device="cuda:0", train_dtype=torch.float16)
+        net.load_keras_params(params)
+        tr = Trainer(net, batch=N, loss="triplet", alpha=0.2, lr=0.01)
+        tr.set_images(x)
+        tr.step_eager()
+        torch.cuda.synchronize()
+        results.append((tr.emb.clone(), tr.G.clone()))
+        tiles.append(dict(tr.tiles))
+    assert tiles[0] == {} and len(tiles[2]) > 200 and all(t // 1000 in (128, 64, 32) and t % 1000 in (128, 64, 32) for t in tiles[2].values())
+    assert tiles[3] == tiles[2] and cache.is_file()                    # second tuned trainer: read back, not re-timed
+    floor = (_rel(results[1][0], results[0][0]), _rel(results[1][1], results[0][1]))
+    for r in results[2:]:
+        d = (_rel(r[0], results[0][0]), _rel(r[1], results[0][1]))
+        assert d[0] <= 3 * floor[0] + 2e-3 and d[1] <= 3 * floor[1] + 2e-2, (d, floor)
