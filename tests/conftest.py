@@ -1,8 +1,6 @@
 import os
 import sys
 
-import os
-
 import pytest
 
 # plans in the tests use the library tile heuristic (deterministic, fast); the tuner has its own test
