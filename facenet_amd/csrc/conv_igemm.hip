@@ -983,8 +983,9 @@ static void choose_wgrad_tile(int Cout, int KTOT, int& bmw, int& bnw) {
 static int choose_wgrad_splits(int M, int Cout, int KTOT, int bmw, int bnw) {
     const long tiles = (long)cdiv(KTOT, bnw) * cdiv(Cout, bmw);
     const int stages = cdiv(M, 64);
+    static const int stem_wgs = getenv("FN_WG_STEMWGS") ? atoi(getenv("FN_WG_STEMWGS")) : 1024;   // tuning aid
     if (stages >= 1024) {   // long chains (stem): ~1024 workgroups in total, at least 4 stages each
-        int s = (int)((1024 + tiles - 1) / tiles);
+        int s = (int)((stem_wgs + tiles - 1) / tiles);
         if (s > stages / 4) s = stages / 4;
         return s < 1 ? 1 : s;
     }
@@ -1013,8 +1014,11 @@ static void final_wgrad_tile(int Cout, int KTOT, int& bmw, int& bnw) {
 static int plan_wgrad(WgradArgs& a, int want_splits, int bmw, int bnw, bool grouped) {
     int splits = want_splits > 0 ? want_splits : choose_wgrad_splits(a.M, a.Cout, a.KTOT, bmw, bnw);
     if (grouped && want_splits <= 0) {
-        // inside a grouped launch the chip is full anyway: fewer, longer splits (less atomic traffic), >= 8 stages each
-        const int cap = cdiv(cdiv(a.M, 64), 8);
+        // inside a grouped launch the chip is full anyway: fewer, longer splits.  Every split adds one fp32 copy of dW through
+        // global atomics, and that traffic -- not the MFMA work -- is what the launch is made of once X / dY come from L2:
+        // measured 606 / 533 / 510 / 502 / 504 / 591 us for >= 8 / 16 / 32 / 48 / 64 / 96 stages per split
+        static const int min_stages = getenv("FN_WG_MINSTAGES") ? atoi(getenv("FN_WG_MINSTAGES")) : 48;   // tuning aid
+        const int cap = cdiv(cdiv(a.M, 64), min_stages);
         if (splits > cap) splits = cap < 1 ? 1 : cap;
     }
     a.chunk = cdiv(cdiv(a.M, splits), 64) * 64;
