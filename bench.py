@@ -320,10 +320,11 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    loss_warm = trainer.loss_value()
     elapsed = timed(args.steps, True)
+    loss = trainer.loss_value()            # last mined step (the train-only replays below re-fit one batch: not a loss to report)
     n2 = max(5, args.steps // 2)
     elapsed_train = timed(n2, False)
-    loss = trainer.loss_value()
 
     out = None
     if rank == 0:
@@ -340,7 +341,7 @@ def main():
                        "hip_graph": not args.no_graph, "streams": args.streams},
             "value_train_only": round(B * world * n2 / elapsed_train, 1),
             "ms_per_step_train_only": round(1e3 * elapsed_train / n2, 3),
-            "final_loss": round(loss, 5),
+            "loss_after_warmup": round(float(loss_warm), 5), "final_loss": round(loss, 5),
             "model_tflops": round((3 * B + POOL) * FWD_GFLOP_PER_IMAGE * 1e-3 / (ms * 1e-3), 1),
         }
     if rank == 0 and world == 1:
