@@ -137,10 +137,16 @@ def test_pipeline_end_to_end(tmp_path):
     one = loader(db.files[3])
     assert one.shape == (160, 160, 3) and np.array_equal(one.cpu().numpy(), po.resize_with_crop_or_pad(truth[db.files[3]], 160, 160))
     seen = []
-    procs = db.tf_dataset_api(loader, batch_size=16, workers=2, processes=True)     # spawned decode workers: same batches
-    first = next(iter(procs))
-    procs.close()
-    assert np.array_equal(first[0].cpu().numpy(), np.stack([po.resize_with_crop_or_pad(truth[f], 160, 160) for f in db.files[:16]]))
+    want16 = np.stack([po.resize_with_crop_or_pad(truth[f], 160, 160) for f in db.files[:16]])
+    # spawned decode workers writing into pinned shared memory: the default stride is smaller than the 480x640 image in the
+    # first batch (packing fallback, stride grows), a 1 MiB stride holds every image (one H2D copy of the slot)
+    for stride in (300 * 300 * 3, 1 << 20):
+        procs = db.tf_dataset_api(loader, batch_size=16, workers=2, processes=True, max_image_bytes=stride)
+        it = iter(procs)
+        first, second = next(it), next(it)
+        procs.close()
+        assert np.array_equal(first[0].cpu().numpy(), want16)
+        assert np.array_equal(second[0].cpu().numpy(), np.stack([po.resize_with_crop_or_pad(truth[f], 160, 160) for f in db.files[16:32]]))
     for images, labels in db.tf_dataset_api(loader, batch_size=16, workers=4):
         assert images.dtype == torch.uint8 and images.is_cuda and labels.dtype == torch.int64
         seen.append((images.cpu().numpy(), labels.cpu().numpy()))
