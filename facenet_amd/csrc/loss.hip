@@ -74,20 +74,18 @@ __device__ __forceinline__ unsigned hash_u32(unsigned a, unsigned b, unsigned c)
 
 // The distance matrix is bitwise symmetric (same products, same order), so thread a reads COLUMN a
 // (dist[j*n + a]: consecutive threads -> consecutive addresses) instead of its own row.
-// Single workgroup; n <= 1024.  scratch (int32, global): per pair q: [a, p, neg, key(u32), cls] at scratch[8 + 5*q].
+// n <= 1024.  scratch (int32, global): per pair q: [a, p, neg, key(u32), cls] at scratch[8 + 5*q].
 // info[0] = #pairs, info[1] = #valid (candidate found), info[2] = 1 if fewer pairs than requested triplets,
 // info[3] = call counter: the effective seed is seed + info[3], so a HIP-graph replay (frozen kernel arguments)
 // still draws fresh negatives every step.  The caller zeroes info once.
-__global__ __launch_bounds__(1024) void select_triplets_kernel(const float* __restrict__ dist, const int* __restrict__ labels, int n,
-                                                               float alpha, int T, unsigned seed0, int semi_hard,
-                                                               int* __restrict__ triplets, int* __restrict__ info) {
-    const unsigned seed = seed0 + (unsigned)info[3];
+// Three launches: (A) one workgroup enumerates the anchor-positive pairs, (B) one WAVE per pair -- spread over the chip -- picks
+// the negative, (C) one workgroup ranks the pairs and writes the triplets.  As a single workgroup phase B ran 17 rounds of
+// dependent loads (~70 us of the 85 us kernel).
+__global__ __launch_bounds__(1024) void select_pairs_kernel(const int* __restrict__ labels, int n, int* __restrict__ info) {
     __shared__ int s_lab[1024];
     __shared__ int s_off[1025];
-    __shared__ int s_nvalid;
     const int tid = threadIdx.x;
     int* rec = info + 8;
-    if (tid == 0) s_nvalid = 0;
     for (int i = tid; i < n; i += 1024) s_lab[i] = labels[i];
     __syncthreads();
     // pairs per anchor (a < p, same label), exclusive prefix -> pair ids in row-major order
@@ -100,59 +98,68 @@ __global__ __launch_bounds__(1024) void select_triplets_kernel(const float* __re
     if (tid == 0)
         for (int i = 0; i < n; ++i) s_off[i + 1] += s_off[i];
     __syncthreads();
-    const int Q = s_off[n];
-    // phase 1: thread per anchor writes the (a, p) of its pairs
     if (tid < n) {
         int q = s_off[tid];
         for (int p = tid + 1; p < n; ++p)
             if (s_lab[p] == s_lab[tid]) { rec[5 * q + 0] = tid; rec[5 * q + 1] = p; ++q; }
     }
-    __threadfence_block();
-    __syncthreads();
-    // phase 2: one wave per pair; candidates are counted / picked with 64-wide ballots in index order
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int q = wave; q < Q; q += 16) {
-        const int a = rec[5 * q + 0], p = rec[5 * q + 1];
-        const int la = s_lab[a];
-        const float dap = dist[(long)p * n + a];
-        int c = 0, others = 0;
-        for (int j0 = 0; j0 < n; j0 += 64) {
-            const int j = j0 + lane;
-            const bool oth = (j < n) && (s_lab[j] != la);
-            const float daj = oth ? dist[(long)j * n + a] : 0.f;
-            const bool cand = oth && (daj - dap < alpha) && (!semi_hard || daj > dap);
-            c += __popcll(__ballot(cand));
-            others += __popcll(__ballot(oth));
-        }
-        const bool use_cand = c > 0;
-        int want = use_cand ? (int)(hash_u32(seed, (unsigned)q, 0u) % (unsigned)c)
-                            : (others > 0 ? (int)(hash_u32(seed, (unsigned)q, 2u) % (unsigned)others) : -1);
-        int neg = -1;
-        for (int j0 = 0; j0 < n && want >= 0; j0 += 64) {
-            const int j = j0 + lane;
-            const bool oth = (j < n) && (s_lab[j] != la);
-            const float daj = oth ? dist[(long)j * n + a] : 0.f;
-            const bool hit = use_cand ? (oth && (daj - dap < alpha) && (!semi_hard || daj > dap)) : oth;
-            const unsigned long long m = __ballot(hit);
-            const int cnt = __popcll(m);
-            if (want < cnt) {
-                const int rank = __popcll(m & ((1ull << lane) - 1ull));
-                const unsigned long long sel = __ballot(hit && rank == want);
-                neg = j0 + (int)__ffsll((long long)sel) - 1;
-                want = -1;
-            } else {
-                want -= cnt;
-            }
-        }
-        if (lane == 0) {
-            rec[5 * q + 2] = neg;
-            rec[5 * q + 3] = (int)hash_u32(seed, (unsigned)q, 1u);
-            rec[5 * q + 4] = use_cand ? 0 : 1;
-            if (use_cand) atomicAdd(&s_nvalid, 1);
+    if (tid == 0) {
+        info[0] = s_off[n];
+        info[1] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void select_negatives_kernel(const float* __restrict__ dist, const int* __restrict__ labels, int n,
+                                                               float alpha, unsigned seed0, int semi_hard, int* __restrict__ info) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= info[0]) return;
+    const unsigned seed = seed0 + (unsigned)info[3];
+    int* rec = info + 8;
+    const int a = rec[5 * q + 0], p = rec[5 * q + 1];
+    const int la = labels[a];
+    const float dap = dist[(long)p * n + a];
+    int c = 0, others = 0;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const bool oth = (j < n) && (labels[j] != la);
+        const float daj = oth ? dist[(long)j * n + a] : 0.f;
+        const bool cand = oth && (daj - dap < alpha) && (!semi_hard || daj > dap);
+        c += __popcll(__ballot(cand));
+        others += __popcll(__ballot(oth));
+    }
+    const bool use_cand = c > 0;
+    int want = use_cand ? (int)(hash_u32(seed, (unsigned)q, 0u) % (unsigned)c)
+                        : (others > 0 ? (int)(hash_u32(seed, (unsigned)q, 2u) % (unsigned)others) : -1);
+    int neg = -1;
+    for (int j0 = 0; j0 < n && want >= 0; j0 += 64) {
+        const int j = j0 + lane;
+        const bool oth = (j < n) && (labels[j] != la);
+        const float daj = oth ? dist[(long)j * n + a] : 0.f;
+        const bool hit = use_cand ? (oth && (daj - dap < alpha) && (!semi_hard || daj > dap)) : oth;
+        const unsigned long long m = __ballot(hit);
+        const int cnt = __popcll(m);
+        if (want < cnt) {
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            const unsigned long long sel = __ballot(hit && rank == want);
+            neg = j0 + (int)__ffsll((long long)sel) - 1;
+            want = -1;
+        } else {
+            want -= cnt;
         }
     }
-    __threadfence_block();
-    __syncthreads();  // single workgroup: the records above are visible to every wave after the fence + barrier
+    if (lane == 0) {
+        rec[5 * q + 2] = neg;
+        rec[5 * q + 3] = (int)hash_u32(seed, (unsigned)q, 1u);
+        rec[5 * q + 4] = use_cand ? 0 : 1;
+        if (use_cand) atomicAdd(&info[1], 1);
+    }
+}
+
+__global__ __launch_bounds__(1024) void select_rank_kernel(int T, int* __restrict__ triplets, int* __restrict__ info) {
+    const int tid = threadIdx.x;
+    const int* rec = info + 8;
+    const int Q = info[0];
     // rank by (cls, key, q); rank < T wins slot `rank`
     for (int q = tid; q < Q; q += 1024) {
         const int cls = rec[5 * q + 4];
@@ -171,10 +178,8 @@ __global__ __launch_bounds__(1024) void select_triplets_kernel(const float* __re
         }
     }
     if (tid == 0) {
-        info[0] = Q;
-        info[1] = s_nvalid;
         info[2] = (Q < T) ? 1 : 0;
-        info[3] = (int)(seed - seed0) + 1;
+        info[3] = info[3] + 1;
     }
 }
 
@@ -268,8 +273,11 @@ extern "C" int fn_pairwise_sqdist(const float* xa, const float* xb, float* out, 
 extern "C" int fn_select_triplets(const float* dist, const int32_t* labels, int n, float alpha, int nrof_triplets, uint32_t seed,
                                   int semi_hard, int32_t* triplets, int32_t* info, void* stream) {
     FN_REQUIRE(dist && labels && triplets && info && n > 1 && n <= 1024 && nrof_triplets > 0, "select_triplets: bad arguments (n <= 1024)");
-    hipLaunchKernelGGL(select_triplets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dist, labels, n, alpha, nrof_triplets, seed,
-                       semi_hard, triplets, info);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(select_pairs_kernel, dim3(1), dim3(1024), 0, st, labels, n, info);
+    const int max_pairs = n * (n - 1) / 2;      // upper bound; waves beyond info[0] leave at once
+    hipLaunchKernelGGL(select_negatives_kernel, dim3(cdiv(max_pairs, 4)), dim3(256), 0, st, dist, labels, n, alpha, seed, semi_hard, info);
+    hipLaunchKernelGGL(select_rank_kernel, dim3(1), dim3(1024), 0, st, nrof_triplets, triplets, info);
     return check_launch("select_triplets");
 }
 
