@@ -36,7 +36,8 @@ HBM_PEAK_GBS = 8000.0
 
 def conv_flops(d, op):
     """Algorithmic FLOPs of one launch: 2 * MACs of the layer (SURVEY.md shape table); dgrad/wgrad = the same MACs."""
-    return 2.0 * d.N * d.OH * d.OW * d.Cout * d.KH * d.KW * d.Cin
+    cout = d.Cout + (d.Cout2 if d.dy2 else 0) + (d.Cout3 if d.dy3 else 0)        # sibling sources of a merged 1x1 data gradient
+    return 2.0 * d.N * d.OH * d.OW * cout * d.KH * d.KW * d.Cin
 
 
 def conv_bytes(d, op):

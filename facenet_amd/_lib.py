@@ -34,6 +34,8 @@ class ConvDesc(C.Structure):
         ("nrm_stats", C.c_void_p), ("nrm_beta", C.c_void_p),
         ("nrm_sq_off", C.c_int32), ("nrm_replicas", C.c_int32), ("nrm_rep_stride", C.c_int32), ("nrm_count", C.c_int32),
         ("nrm_eps", C.c_float), ("tile_fwd", C.c_int32), ("tile_dgrad", C.c_int32),
+        ("dy2", C.c_void_p), ("w2", C.c_void_p), ("dy3", C.c_void_p), ("w3", C.c_void_p),
+        ("Cout2", C.c_int32), ("ld_y2", C.c_int32), ("Cout3", C.c_int32), ("ld_y3", C.c_int32),
     ]
 
 

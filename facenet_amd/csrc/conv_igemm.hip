@@ -60,6 +60,11 @@ struct ConvArgs {
     int total_tiles;
     int src_bytes, w_bytes;   // extents for the buffer resource descriptors (< 2^30)
     int tile;                 // 0 = heuristic, BM*1000+BN = caller's choice (fn_conv_desc.tile_fwd / tile_dgrad)
+    // 1x1 data gradient of SIBLING layers that read the same input: dX = sum_s dY_s * Wt_s as ONE GEMM whose K runs through
+    // the sources (k tiles [0,t1) source 1, [t1,t2) source 2, [t2,nt_total) source 3); nt_total == 0: single source
+    const unsigned short* src2; const unsigned short* wp2;
+    const unsigned short* src3; const unsigned short* wp3;
+    int K2, ld2, K3, ld3, t1, t2, nt_total, src2_bytes, w2_bytes, src3_bytes, w3_bytes;
     // normalise-on-load (forward only): src is the raw output of a BN(center)+ReLU layer, see fn_conv_desc.nrm_*
     const float* nrm_stats;
     const float* nrm_beta;
@@ -95,9 +100,13 @@ __device__ __forceinline__ int ktab_entry(int kgroup, int KTOT, int CS, int KW) 
 // LDS staging buffers, the partial accumulators are summed through LDS into group 0, which runs the epilogue.  The layers
 // on the 17x17 / 8x8 / 3x3 maps have a few hundred workgroups and 9-36 k tiles each: their run time is the length of that
 // serial chain, and a CU has wave slots to spare.
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, bool NORM>
+// MODE: 0 = ordinary, 1 = normalise-on-load operand (NORM), 2 = sibling sources for a 1x1 data gradient (MULTI).  The extra
+// descriptors of mode 2 cost 16 SGPRs: as a run-time option they pushed every 1x1 kernel into SGPR spills.
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, int MODE>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid) {
-    static_assert(KS == 1 || !NORM, "normalise-on-load is built for KS == 1 only");
+    constexpr bool NORM = MODE == 1, MULTI = MODE == 2;
+    static_assert(KS == 1 || MODE == 0, "normalise-on-load / sibling sources are built for KS == 1 only");
+    static_assert(!MULTI || PLAIN, "sibling sources are 1x1 layers");
     constexpr int NT = 256 * KS;
     constexpr int BK = 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -140,7 +149,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         rcp_divmod(tile, a.tiles_n, tm, tn);
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int ntiles_k = (ktot + BK - 1) / BK;
+    const int ntiles_k = MULTI ? a.nt_total : (ktot + BK - 1) / BK;
     int* sRow = reinterpret_cast<int*>(sT + (PLAIN ? 0 : ((a.KTOT + BK - 1) / BK) * 8));   // [BM] output pixel of every tile row (class mode)
     float* sNs = reinterpret_cast<float*>(sRow + BM);   // NORM: [CS] scale, [CS] shift of the source channels
     float* sNh = sNs + a.CS;
@@ -230,6 +239,33 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     auto load_tile = [&](int kt, u32x4 (&ra)[AP], u32x4 (&rb)[BP], unsigned& msk) {
         unsigned mk = 0u;
         if constexpr (PLAIN) {
+            if constexpr (MULTI) {   // pick the source of this k tile (uniform), same two loads per row as below
+                const int s = kt >= a.t2 ? 2 : (kt >= a.t1 ? 1 : 0);
+                const int tb = s == 2 ? a.t2 : (s == 1 ? a.t1 : 0);
+                const int Ks = s == 2 ? a.K3 : (s == 1 ? a.K2 : a.KTOT);
+                const unsigned lds = (unsigned)(s == 2 ? a.ld3 : (s == 1 ? a.ld2 : a.ld_src));
+                // descriptors are rebuilt per tile from the selected pointer (scalar work): six live descriptors spill SGPRs
+                const unsigned short* ps = s == 2 ? a.src3 : (s == 1 ? a.src2 : a.src);
+                const unsigned short* pw = s == 2 ? a.wp3 : (s == 1 ? a.wp2 : a.wp);
+                const int bs = s == 2 ? a.src3_bytes : (s == 1 ? a.src2_bytes : a.src_bytes);
+                const int bw = s == 2 ? a.w3_bytes : (s == 1 ? a.w2_bytes : a.w_bytes);
+                const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(ps), 0, bs, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(pw), 0, bw, 0x00020000);
+                const int kk = (kt - tb) * BK + kg * 8;
+                const unsigned kb = kk < Ks ? (unsigned)kk * 2u : OOB;
+#pragma unroll
+                for (int i = 0; i < AP; ++i) {
+                    const unsigned m2 = (unsigned)(m0 + r0 + 32 * i) * 2u;
+                    const unsigned off = rbyte[i] < 0x40000000u ? m2 * lds + kb : OOB;
+                    ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, (int)off, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < BP; ++j) {
+                    const unsigned co2 = (unsigned)(n0 + r0 + 32 * j) * 2u;
+                    const unsigned off = wbyte[j] < 0x40000000u ? co2 * (unsigned)Ks + kb : OOB;
+                    rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)off, 0, 0);
+                }
+            } else {
             const int kk = kt * BK + kg * 8;
             const unsigned kb = kk < a.KTOT ? (unsigned)kk * 2u : OOB;
 #pragma unroll
@@ -239,6 +275,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             }
 #pragma unroll
             for (int j = 0; j < BP; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wbyte[j] + kb), 0, 0);
+            }
         } else {
             const int4 t = sT[kt * 8 + kg];
             const int dy = t.x >> 24, dx = (int)((unsigned)t.x << 8) >> 24;
@@ -517,21 +554,21 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, bool NORM>
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, int MODE>
 __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(const ConvArgs a) {
-    conv_igemm_body<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, NORM>(a, blockIdx.x);
+    conv_igemm_body<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, MODE>(a, blockIdx.x);
 }
 
 // Grouped form: one launch runs several INDEPENDENT convolutions of one tile variant (sibling inception towers, the
 // same dependency level of the launch list): args[g] is layer g, prefix[g] .. prefix[g+1] its workgroups.
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, bool NORM>
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, int MODE>
 __global__ __launch_bounds__(256 * KS) void conv_igemm_grouped_kernel(const ConvArgs* __restrict__ args, const int* __restrict__ prefix, int n) {
     const int bid = blockIdx.x;
     int g = 0;
     while (g + 1 < n && prefix[g + 1] <= bid) ++g;     // n is small (<= 8)
     g = __builtin_amdgcn_readfirstlane(g);             // provably wave-uniform: args[g] is fetched with scalar loads into SGPRs
     const ConvArgs a = args[g];
-    conv_igemm_body<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, NORM>(a, bid - prefix[g]);
+    conv_igemm_body<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, MODE>(a, bid - prefix[g]);
 }
 
 // tiles of a launch; in class mode (stride-2 dgrad) every parity class has its own row tiles
@@ -567,9 +604,9 @@ static size_t conv_smem_bytes(int BM, int BN, int KTOT, int plain, int norm_chan
            (size_t)norm_channels * 8;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, bool NORM>
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, int MODE>
 static int launch_conv_grouped_p(const ConvArgs* dev_args, const int32_t* dev_prefix, int n, int total, size_t smem, hipStream_t st) {
-    auto kern = conv_igemm_grouped_kernel<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, NORM>;
+    auto kern = conv_igemm_grouped_kernel<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, MODE>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -579,16 +616,16 @@ static int launch_conv_grouped_p(const ConvArgs* dev_args, const int32_t* dev_pr
     return check_launch("conv_igemm_grouped");
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, bool NORM>
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, int MODE>
 static int launch_conv_p(const ConvArgs& a0, hipStream_t st) {
     ConvArgs a = a0;
     plan_tiles(a, BM, BN);
-    const size_t smem = conv_smem_bytes(BM, BN, a.KTOT, PLAIN ? 1 : 0, NORM ? a.CS : 0, KS);
+    const size_t smem = conv_smem_bytes(BM, BN, a.KTOT, PLAIN ? 1 : 0, MODE == 1 ? a.CS : 0, KS);
     if (smem > 160 * 1024) {
         set_error("conv: K=%d needs %zu B of LDS (>160 KiB)", a.KTOT, smem);
         return FN_EUNSUPPORTED;
     }
-    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, NORM>;
+    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, MODE>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -601,10 +638,11 @@ static int launch_conv_p(const ConvArgs& a0, hipStream_t st) {
 template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
     if constexpr (KS == 1) {
+        if (a.nt_total > 0) return launch_conv_p<T, BM, BN, WM, WN, DEPTH, 1, true, 2>(a, st);
         if (a.nrm_stats)
-            return a.plain ? launch_conv_p<T, BM, BN, WM, WN, DEPTH, 1, true, true>(a, st) : launch_conv_p<T, BM, BN, WM, WN, DEPTH, 1, false, true>(a, st);
+            return a.plain ? launch_conv_p<T, BM, BN, WM, WN, DEPTH, 1, true, 1>(a, st) : launch_conv_p<T, BM, BN, WM, WN, DEPTH, 1, false, 1>(a, st);
     }
-    return a.plain ? launch_conv_p<T, BM, BN, WM, WN, DEPTH, KS, true, false>(a, st) : launch_conv_p<T, BM, BN, WM, WN, DEPTH, KS, false, false>(a, st);
+    return a.plain ? launch_conv_p<T, BM, BN, WM, WN, DEPTH, KS, true, 0>(a, st) : launch_conv_p<T, BM, BN, WM, WN, DEPTH, KS, false, 0>(a, st);
 }
 
 // Tile choice.  BN: smallest padded width, ties -> larger tile.  BM: the largest of {128, 64, 32} that still gives
@@ -667,7 +705,7 @@ template <typename T> static int dispatch_conv(const ConvArgs& a, hipStream_t st
         int fm = 0, fnn = 0;
         if (sscanf(f, "%dx%d", &fm, &fnn) == 2) { bm = fm; bn = fnn; }
     }
-    const int ks = a.nrm_stats ? 1 : choose_conv_ks(a.M, a.NOUT, a.KTOT, bm, bn);
+    const int ks = (a.nrm_stats || a.nt_total > 0) ? 1 : choose_conv_ks(a.M, a.NOUT, a.KTOT, bm, bn);
 #define FN_X(BM_, BN_, WM_, WN_, D_, KS_) \
     if (bm == BM_ && bn == BN_ && ks == KS_) return launch_conv<T, BM_, BN_, WM_, WN_, D_, KS_>(a, st);
     FN_CONV_VARIANTS(FN_X)
@@ -685,11 +723,11 @@ static int dispatch_conv_grouped(const ConvArgs* dev_args, const int32_t* dev_pr
     if (bm == BM_ && bn == BN_ && ks == KS_) {                                                                                                  \
         if constexpr (KS_ == 1) {                                                                                                               \
             if (norm)                                                                                                                           \
-                return plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, 1, true, true>(dev_args, dev_prefix, n, total, smem, st)         \
-                             : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, 1, false, true>(dev_args, dev_prefix, n, total, smem, st);       \
+                return plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, 1, true, 1>(dev_args, dev_prefix, n, total, smem, st)         \
+                             : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, 1, false, 1>(dev_args, dev_prefix, n, total, smem, st);       \
         }                                                                                                                                       \
-        return plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, KS_, true, false>(dev_args, dev_prefix, n, total, smem, st)              \
-                     : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, KS_, false, false>(dev_args, dev_prefix, n, total, smem, st);            \
+        return plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, KS_, true, 0>(dev_args, dev_prefix, n, total, smem, st)              \
+                     : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, KS_, false, 0>(dev_args, dev_prefix, n, total, smem, st);            \
     }
     FN_CONV_VARIANTS(FN_X)
 #undef FN_X
@@ -1096,6 +1134,24 @@ static int make_dgrad_args(const fn_conv_desc* d, ConvArgs& a) {
     a.w_bytes = d->Cin * a.KTOT * 2;
     FN_REQUIRE(valid_tile(d->tile_dgrad), "conv_dgrad: tile_dgrad=%d is not one of {128,64,32}x{128,64,32}", d->tile_dgrad);
     a.tile = d->tile_dgrad;
+    if (d->dy2) {   // sibling sources
+        FN_REQUIRE(a.plain && d->w2 && d->Cout2 > 0 && d->Cout2 % 8 == 0 && d->ld_y2 % 8 == 0 && d->ld_y2 >= d->Cout2 && !d->bn_y,
+                   "conv_dgrad: sibling sources need a 1x1 stride-1 layer, w2 and Cout2/ld_y2 multiples of 8");
+        FN_REQUIRE(!d->dy3 || (d->w3 && d->Cout3 > 0 && d->Cout3 % 8 == 0 && d->ld_y3 % 8 == 0 && d->ld_y3 >= d->Cout3),
+                   "conv_dgrad: third source needs w3 and Cout3/ld_y3 multiples of 8");
+        const long pix = (long)d->N * d->OH * d->OW;
+        FN_REQUIRE(pix * d->ld_y2 * 2 < (1L << 30) && (!d->dy3 || pix * d->ld_y3 * 2 < (1L << 30)), "conv_dgrad: sibling dy exceeds 1 GiB");
+        a.src2 = (const unsigned short*)d->dy2; a.wp2 = (const unsigned short*)d->w2; a.K2 = d->Cout2; a.ld2 = d->ld_y2;
+        a.src2_bytes = (int)(pix * d->ld_y2 * 2); a.w2_bytes = d->Cin * d->Cout2 * 2;
+        a.t1 = cdiv(a.KTOT, 64);
+        a.t2 = a.t1 + cdiv(a.K2, 64);
+        a.nt_total = a.t2;
+        if (d->dy3) {
+            a.src3 = (const unsigned short*)d->dy3; a.wp3 = (const unsigned short*)d->w3; a.K3 = d->Cout3; a.ld3 = d->ld_y3;
+            a.src3_bytes = (int)(pix * d->ld_y3 * 2); a.w3_bytes = d->Cin * d->Cout3 * 2;
+            a.nt_total = a.t2 + cdiv(a.K3, 64);
+        }
+    }
     if (d->bn_y) {
         FN_REQUIRE(!d->accumulate && !d->out_f32 && d->bn_scale && d->bn_shift && d->bn_beta && d->bn_acc && d->ld_bn_y % 8 == 0,
                    "conv_dgrad: fused BN reduction needs a sole-writer low-precision dx and all bn_* pointers");
@@ -1141,6 +1197,7 @@ extern "C" int fn_conv2d_group_build(const fn_conv_desc* descs, int n, int op, i
         FN_REQUIRE(m == bm && k == bn && ksi == ks, "conv_group_build: descriptor %d dispatches to %dx%d ks=%d, group is %dx%d ks=%d", i, m, k,
                    ksi, bm, bn, ks);
         FN_REQUIRE(descs[i].dtype == descs[0].dtype, "conv_group_build: mixed dtypes");
+        FN_REQUIRE(a.nt_total == 0, "conv_group_build: a data gradient with sibling sources is a launch of its own");
         const int pl = a.plain | (a.nrm_stats ? 2 : 0);
         if (plain0 < 0) plain0 = pl;
         FN_REQUIRE(pl == plain0, "conv_group_build: 1x1 / general / normalise-on-load convolutions cannot share a group");
@@ -1267,7 +1324,7 @@ extern "C" int fn_conv2d_variant(const fn_conv_desc* d, int op) {
     }
     if (op == 1) {
         choose_conv_tile(d->N * d->H * d->W, d->Cin, valid_tile(d->tile_dgrad) ? d->tile_dgrad : 0, a, b);
-        return variant_code(a, b, choose_conv_ks(d->N * d->H * d->W, d->Cin, d->KH * d->KW * d->Cout, a, b));
+        return variant_code(a, b, d->dy2 ? 1 : choose_conv_ks(d->N * d->H * d->W, d->Cin, d->KH * d->KW * d->Cout, a, b));
     }
     final_wgrad_tile(d->Cout, d->KH * d->KW * d->Cin, a, b);
     return a * 1000 + b;

@@ -387,6 +387,7 @@ class Lowering:
         # launches and the activated copies, but every tap and every N tile repeats the per-element affine+ReLU, which makes
         # the staging VALU-bound: measured 9.52 ms vs 9.11 ms per step on MI355X -> off by default.
         self.norm_on_load = bool(int(os.environ.get("FACENET_NORM_ON_LOAD", "0")))
+        self.merge_sibling_dgrads = bool(int(os.environ.get("FACENET_MERGE_SIBLINGS", "1")))
         self.virtual: Dict[str, List[Tuple[int, int]]] = {}     # buffer -> [(c0, C)] BN ranges that are not materialised
         self.dtype = net.train_dtype if training else net.infer_dtype
         self.dt = None if declare else _lib.dtype_code(self.dtype)
@@ -745,6 +746,17 @@ class Lowering:
             b.grad_ranges = []
         self._demb = demb
         self._dup: Dict[str, torch.Tensor] = {}
+        # sibling 1x1 stride-1 layers reading the same trunk slice (the first convolutions of inception towers): their data
+        # gradients all accumulate into that slice -- emitted as ONE multi-source launch when the last of them is reached
+        self._siblings: Dict[Tuple[str, int, int], List[Rec]] = {}
+        self._sib_pending: Dict[Tuple[str, int, int], list] = {}
+        if self.merge_sibling_dgrads:
+            for r in self.recs:
+                L = r.layer
+                if (r.kind == "conv" and r.extra.get("kind") == "bn" and L.kh == 1 and L.kw == 1 and L.stride == 1 and L.pad_h == 0
+                        and L.pad_w == 0 and r.x.buf.name != "input" and not self.bn_ranges.get(r.x.buf.name)):
+                    self._siblings.setdefault((r.x.buf.name, r.x.c0, r.x.C), []).append(r)
+            self._siblings = {k: v for k, v in self._siblings.items() if 2 <= len(v) <= 3}
         for r in reversed(self.recs):
             getattr(self, "_bwd_" + r.kind)(r)
 
@@ -791,7 +803,27 @@ class Lowering:
         d.dw = _ptr(net.G, L.w_off)
         self._emit(self.bwd, "conv_wgrad:" + L.name, lib.fn_conv2d_wgrad, C.byref(d), keep=(d,),
                    r=wreads, w=[region(net.G, L.w_off, L.w_off + L.numel)])
-        if x.buf.name != "input":
+        sib_key = (x.buf.name, x.c0, x.C)
+        if sib_key in self._siblings and any(r is m for m in self._siblings[sib_key]):
+            pend = self._sib_pending.setdefault(sib_key, [])
+            pend.append((L, dy_ptr, ld_dy, dy_reg))
+            if len(pend) == len(self._siblings[sib_key]):
+                (L0, p0, ld0, reg0), rest = pend[0], pend[1:]
+                g = self._desc(L0, x, y)
+                g.Cout, g.ld_y, g.y = L0.cout, ld0, p0
+                g.w = _ptr(net.Wt_train, L0.w_off)
+                g.dx = _ptr(x.buf.grad, x.c0)
+                g.accumulate = self._grad_mode(x)
+                rd = [reg0, region(net.Wt_train, L0.w_off, L0.w_off + L0.numel)]
+                for i, (Li, pi, ldi, regi) in enumerate(rest):
+                    setattr(g, ("dy2", "dy3")[i], pi)
+                    setattr(g, ("w2", "w3")[i], _ptr(net.Wt_train, Li.w_off))
+                    setattr(g, ("Cout2", "Cout3")[i], Li.cout)
+                    setattr(g, ("ld_y2", "ld_y3")[i], ldi)
+                    rd += [regi, region(net.Wt_train, Li.w_off, Li.w_off + Li.numel)]
+                self._emit(self.bwd, "conv_dgrad:" + "+".join(p[0].name for p in pend), lib.fn_conv2d_dgrad, C.byref(g), keep=(g,),
+                           r=rd, w=[self._rg(x)])
+        elif x.buf.name != "input":
             g = self._desc(L, x, y)
             g.ld_y = ld_dy
             g.y = dy_ptr

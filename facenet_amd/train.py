@@ -163,7 +163,7 @@ def group_convs(ops: List[Op], net: Network) -> List[Op]:
     for i in order:
         op = ops[i]
         kind = op.name.split(":")[0]
-        if kind in ("conv_fwd", "conv_dgrad") and op.keep and isinstance(op.keep[0], _lib.ConvDesc):
+        if kind in ("conv_fwd", "conv_dgrad") and op.keep and isinstance(op.keep[0], _lib.ConvDesc) and not op.keep[0].dy2:
             d = op.keep[0]
             opi = 0 if kind == "conv_fwd" else 1
             plain = int(d.KH == 1 and d.KW == 1 and d.stride == 1 and d.pad_h == 0 and d.pad_w == 0)

@@ -78,6 +78,15 @@ typedef struct fn_conv_desc {
      * times the candidates once per plan: facenet_amd/engine.py autotune).  Results do not depend on the tile beyond the
      * summation order. */
     int32_t tile_fwd, tile_dgrad;
+    /* dgrad of SIBLING 1x1 stride-1 layers that read the same x (inception towers branching off one trunk): dX = y-gradient of
+     * this layer times its transposed pack PLUS the same for up to two more layers (dy2/w2, dy3/w3; their Cout and dy row
+     * stride), computed as one GEMM whose K runs through the sources -- one launch and one pass over dX instead of a chain of
+     * read-modify-write accumulations.  dy2 == NULL: ordinary single layer. */
+    const void* dy2;
+    const void* w2;
+    const void* dy3;
+    const void* w3;
+    int32_t Cout2, ld_y2, Cout3, ld_y3;
 } fn_conv_desc;
 
 int fn_conv2d_fwd(const fn_conv_desc* d, void* stream);

@@ -300,3 +300,37 @@ def test_conv_normalise_on_load_rejects_wide_inputs(lib):
     d.x, d.w, d.y, d.nrm_stats, d.nrm_beta, d.nrm_count, d.nrm_eps, d.nrm_sq_off = ptr(x), ptr(w), ptr(y), ptr(st), ptr(st), 9, 1e-3, 1792
     with pytest.raises(ValueError):
         _lib.check(lib.fn_conv2d_fwd(C.byref(d), stream()))
+
+
+@pytest.mark.parametrize("dt", [_lib.FN_BF16, _lib.FN_F16])
+@pytest.mark.parametrize("nsrc", [2, 3])
+@pytest.mark.parametrize("tile", [0, 128064, 64064, 32032, 32128])
+def test_dgrad_sibling_sources_equal_the_sum_of_single_dgrads(lib, dt, nsrc, tile):
+    """dX of 2-3 sibling 1x1 layers as ONE multi-source launch (dy2/w2, dy3/w3, own row strides and widths, K tails that are
+    not multiples of the 64-wide k tile) == the fp32 sum of the per-layer products, with and without accumulation."""
+    N, H, W, Cin = 3, 9, 9, 256
+    couts, lds = [32, 40, 96][:nsrc], [96, 40, 160][:nsrc]          # dY slices of wider buffers (ld > Cout) like `mixed`
+    M = N * H * W
+    dys = [_mk((N, H, W, ld), dt, seed=20 + i) for i, ld in enumerate(lds)]
+    wts = [_mk((Cin, 1, 1, c), dt, 0.1, seed=30 + i) for i, c in enumerate(couts)]      # transposed packs [Cin][tap][Cout]
+    ref = sum(dy[..., :c].float().cpu().reshape(M, c) @ wt.float().cpu().reshape(Cin, c).t() for dy, wt, c in zip(dys, wts, couts))
+    d = conv_desc(N, H, W, Cin, couts[0], 1, 1, 1, 0, 0, dt, ld_y=lds[0])
+    d.tile_dgrad = tile
+    d.y, d.w = ptr(dys[0]), ptr(wts[0])
+    d.dy2, d.w2, d.Cout2, d.ld_y2 = ptr(dys[1]), ptr(wts[1]), couts[1], lds[1]
+    if nsrc == 3:
+        d.dy3, d.w3, d.Cout3, d.ld_y3 = ptr(dys[2]), ptr(wts[2]), couts[2], lds[2]
+    dx = torch.full((N, H, W, Cin), 3.0, dtype=lp_dtype(dt), device="cuda")
+    d.dx = ptr(dx)
+    _lib.check(lib.fn_conv2d_dgrad(C.byref(d), stream()))
+    torch.cuda.synchronize()
+    tol = 6e-3 if dt == _lib.FN_BF16 else 8e-4
+    assert rel_err(dx.reshape(M, Cin), ref) < tol
+    base = dx.float().cpu().reshape(M, Cin).clone()
+    d.accumulate = 1
+    _lib.check(lib.fn_conv2d_dgrad(C.byref(d), stream()))
+    torch.cuda.synchronize()
+    assert rel_err(dx.reshape(M, Cin), base + ref) < 2 * tol
+    d.Cout2 = 33                                                    # not a multiple of 8
+    with pytest.raises(ValueError):
+        _lib.check(lib.fn_conv2d_dgrad(C.byref(d), stream()))
