@@ -754,7 +754,7 @@ class Lowering:
             for r in self.recs:
                 L = r.layer
                 if (r.kind == "conv" and r.extra.get("kind") == "bn" and L.kh == 1 and L.kw == 1 and L.stride == 1 and L.pad_h == 0
-                        and L.pad_w == 0 and r.x.buf.name != "input" and not self.bn_ranges.get(r.x.buf.name)):
+                        and L.pad_w == 0 and r.x.buf.name != "input"):
                     self._siblings.setdefault((r.x.buf.name, r.x.c0, r.x.C), []).append(r)
             self._siblings = {k: v for k, v in self._siblings.items() if 2 <= len(v) <= 3}
         for r in reversed(self.recs):
