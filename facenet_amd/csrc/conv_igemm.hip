@@ -691,7 +691,7 @@ static int choose_conv_ks(int M, int NOUT, int KTOT, int bm, int bn) {
 }
 
 // tile variants: BM, BN, waves (M x N), register stages, split-K groups
-#define FN_CONV_VARIANTS(X) X(128, 128, 2, 2, 1, 1) X(128, 64, 2, 2, 1, 1) X(128, 32, 4, 1, 1, 1) X(64, 128, 1, 4, 2, 1) X(64, 64, 2, 2, 2, 1) \
+#define FN_CONV_VARIANTS(X) X(128, 128, 2, 2, 1, 1) X(128, 64, 2, 2, 2, 1) X(128, 32, 4, 1, 2, 1) X(64, 128, 1, 4, 2, 1) X(64, 64, 2, 2, 2, 1) \
     X(64, 32, 2, 2, 2, 1) X(32, 128, 1, 4, 4, 1) X(32, 64, 1, 4, 4, 1) X(32, 32, 2, 2, 4, 1)                                           \
     X(32, 128, 1, 4, 4, 2) X(32, 64, 1, 4, 4, 2) X(32, 64, 1, 4, 4, 4) X(32, 32, 2, 2, 4, 2) X(32, 32, 2, 2, 4, 4)
 
