@@ -61,26 +61,30 @@ def event_pair_overhead_ms(n=200):
     return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
 
-def time_ops_individually(ops, stream, lib, reps=3):
-    """HIP events around every launch (on the stream the kernels run on); returns per-op best-of-reps milliseconds, net of
-    the empty event-pair overhead."""
+def time_ops_individually(ops, stream, lib, reps=3, burst=4):
+    """HIP events around a short burst of back-to-back launches of every op (on the stream the kernels run on); returns the
+    per-launch MEAN in milliseconds, net of the empty event-pair overhead (amortised over the burst).  A burst, not a single
+    launch: the event bookkeeping is several microseconds, comparable to the small kernels themselves, and this is what
+    makes the figures agree with rocprofv3's per-kernel averages.  What repeated launches accumulate (BN statistics, dW) is
+    re-zeroed by the next real step."""
     from facenet_amd import _lib
-    times = [float("inf")] * len(ops)
+    sums = [0.0] * len(ops)
     for _ in range(reps):
         evs = []
         for op in ops:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            rc = op.fn(*op.args, stream)
+            for _ in range(burst):
+                rc = op.fn(*op.args, stream)
+                if rc:
+                    _lib.check(rc, op.name)
             b.record()
-            if rc:
-                _lib.check(rc, op.name)
             evs.append((a, b))
         torch.cuda.synchronize()
         for i, (a, b) in enumerate(evs):
-            times[i] = min(times[i], a.elapsed_time(b))
+            sums[i] += a.elapsed_time(b)
     ovh = event_pair_overhead_ms()
-    return [max(t - ovh, 1e-4) for t in times]
+    return [max((t / reps - ovh) / burst, 1e-4) for t in sums]
 
 
 def _mangle_hint(demangled):

@@ -19,6 +19,7 @@ def main():
             fh.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline   (MI355X, round 1, final state)\n")
             fh.write("# the run = autotune bursts + warm-up + capture + 20 timed + 10 train-only graph replays + ONE eager per-launch timing pass;\n")
             fh.write(f"# durations are per kernel launch.  Total kernel time {total / 1e3:.1f} ms.  Names are mangled: IDF16b = __bf16, IDF16_ = _Float16,\n")
+            fh.write("# rocprofv3 durations carry ~3 us of per-dispatch floor (adam_tick_kernel: one thread, ~4.7 us here; 1.8 us per launch in a replayed graph).\n")
             fh.write("# conv_igemm template arguments = BM, BN, waves M, waves N, register stages, split-K groups, 1x1 fast path, normalise-on-load.\n\n")
             fh.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
             for r in sorted(rows, key=lambda r: -r[2])[:30]:
