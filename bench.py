@@ -109,8 +109,8 @@ def pmc_traffic(kernel_key):
     tname = "DF16b" if m.group(2) == "__bf16" else "DF16_"
     if "wgrad" in m.group(1):      # <T, BMW, BNW, NORM>
         pat = re.compile(rf"{m.group(1)}I{tname}Li{m.group(3)}ELi{m.group(4)}ELb0EE")
-    else:                          # <T, BM, BN, WM, WN, DEPTH, KS, PLAIN, NORM>
-        pat = re.compile(rf"{m.group(1)}I{tname}Li{m.group(3)}ELi{m.group(4)}ELi\d+ELi\d+ELi\d+ELi{m.group(5) or 1}ELb{m.group(6)}ELb0EE")
+    else:                          # <T, BM, BN, WM, WN, DEPTH, KS, PLAIN, MODE>
+        pat = re.compile(rf"{m.group(1)}I{tname}Li{m.group(3)}ELi{m.group(4)}ELi\d+ELi\d+ELi\d+ELi{m.group(5) or 1}ELb{m.group(6)}ELi0EE")
     n = tot = 0.0
     for name, v in json.load(open(path))["kernels"].items():
         if pat.search(name) or pat.search(_mangle_hint(name)):
