@@ -38,3 +38,9 @@ for tile in (128064, 64064):
 print("4a 37x37x80->192 3x3, 128x64")
 for N in (2, 8, 34, 136, 180):
     bench(N, 37, 37, 80, 192, 3, 3, 1, 0, 0, 128064)
+print("per-tile fixed vs per-k-tile cost, 128x64 tiles, N=180 77x77xCin->64 3x3")
+for cin in (32, 64, 128, 256):
+    bench(180, 77, 77, cin, 64, 3, 3, 1, 0, 0, 128064)
+print("same, 64x64 tiles")
+for cin in (32, 64, 128, 256):
+    bench(180, 77, 77, cin, 64, 3, 3, 1, 0, 0, 64064)
