@@ -42,7 +42,7 @@ def train_tripletloss(cfg, people_per_batch: int = 45, images_per_person: int = 
         miner.run()
         ev = make_events(miner.sched)
         mine_graph = GraphRunner(net.device).capture(lambda: miner.run(ev))
-        trainer.capture()
+        trainer.capture()                                         # side-effect free (state restored after its warm-up step)
     for epoch in range(cfg.train.epoch.nrof_epochs):
         trainer.set_learning_rate(scheduler(epoch))
         t0 = time.perf_counter()

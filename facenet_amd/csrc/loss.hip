@@ -234,8 +234,11 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
     if (lane == 0) red[wave] = s;
     __syncthreads();
     s = red[0] + red[1] + red[2] + red[3];
+    // an out-of-range class index never indexes the logits: the loss becomes NaN (what TF's GPU kernel returns; its CPU kernel
+    // raises, which Trainer.set_images does on the host) and the row contributes no one-hot term
     const int lab = labels[row];
-    if (tid == 0) atomicAdd(loss, (logf(s) + mx - x[lab]) / (float)N);
+    const bool lab_ok = lab >= 0 && lab < C;
+    if (tid == 0) atomicAdd(loss, lab_ok ? (logf(s) + mx - x[lab]) / (float)N : __builtin_nanf(""));
     if (dlogits) {
         const float inv = 1.f / s;
         unsigned short* d = dlogits + (long)row * ld_d;

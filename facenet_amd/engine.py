@@ -47,6 +47,33 @@ DEFAULT_CONFIG = {   # inception_resnet_v1.py:13-43
 }
 
 
+# tower declarations (name, filters, kernel[, stride, padding]) of the residual and reduction blocks
+# (inception_resnet_v1.py:83-259 and :262-377); shared by the full network and by BlockNetwork
+BLOCK_TOWERS = {
+    "block35": ([[("Conv2d_1x1", 32, (1, 1))],
+                 [("Conv2d_0a_1x1", 32, (1, 1)), ("Conv2d_0b_3x3", 32, (3, 3))],
+                 [("Conv2d_0a_1x1", 32, (1, 1)), ("Conv2d_0b_3x3", 32, (3, 3)), ("Conv2d_0c_3x3", 32, (3, 3))]], 256),
+    "block17": ([[("Conv2d_1x1", 128, (1, 1))],
+                 [("Conv2d_0a_1x1", 128, (1, 1)), ("Conv2d_0b_1x7", 128, (1, 7)), ("Conv2d_0c_7x1", 128, (7, 1))]], 896),
+    "block8": ([[("Conv2d_1x1", 192, (1, 1))],
+                [("Conv2d_0a_1x1", 192, (1, 1)), ("Conv2d_0b_1x3", 192, (1, 3)), ("Conv2d_0c_3x1", 192, (3, 1))]], 1792),
+}
+
+
+def reduction_towers(kind: str, filters):
+    if kind == "reduction_a":
+        fa = filters
+        return [[("Conv2d_1a_3x3", fa[0][0], (3, 3), 2, "valid")],
+                [("Conv2d_0a_1x1", fa[1][0], (1, 1), 1, "same"), ("Conv2d_0b_3x3", fa[1][1], (3, 3), 1, "same"),
+                 ("Conv2d_1a_3x3", fa[1][2], (3, 3), 2, "valid")]]
+    fb = filters
+    return [[("Conv2d_0a_1x1", fb[0][0], (1, 1), 1, "same"), ("Conv2d_1a_3x3", fb[0][1], (3, 3), 2, "valid")],
+            [("Conv2d_0a_1x1", fb[1][0], (1, 1), 1, "same"), ("Conv2d_1a_3x3", fb[1][1], (3, 3), 2, "valid")],
+            [("Conv2d_0a_1x1", fb[2][0], (1, 1), 1, "same"), ("Conv2d_0b_3x3", fb[2][1], (3, 3), 1, "same"),
+             ("Conv2d_1a_3x3", fb[2][2], (3, 3), 2, "valid")]]
+
+
+
 def _pad8(c: int) -> int:
     return (c + 7) // 8 * 8
 
@@ -172,31 +199,18 @@ class Network:
         x = g.cbr("conv2d/Conv2d_3b_1x1", x, 80, (1, 1), 1, "valid")                   # :410
         x = g.cbr("conv2d/Conv2d_4a_3x3", x, 192, (3, 3), 1, "valid")                  # :417
         x = g.cbr("conv2d/Conv2d_4b_3x3", x, 256, (3, 3), 2, "valid")                  # :424
-        b35 = [[("Conv2d_1x1", 32, (1, 1))],
-               [("Conv2d_0a_1x1", 32, (1, 1)), ("Conv2d_0b_3x3", 32, (3, 3))],
-               [("Conv2d_0a_1x1", 32, (1, 1)), ("Conv2d_0b_3x3", 32, (3, 3)), ("Conv2d_0c_3x3", 32, (3, 3))]]
+        b35, up35 = BLOCK_TOWERS["block35"]
         for i in range(cfg["block35"]["repeat"]):                                      # :433-435 ; relu hard-coded :88
-            x = g.block(f"block35/{i}", x, b35, 256, cfg["block35"]["scale"], True)
-        fa = cfg["reduction_a"]["filters"]                                              # :262-307
-        x = g.reduction("reduction_a", x, [
-            [("Conv2d_1a_3x3", fa[0][0], (3, 3), 2, "valid")],
-            [("Conv2d_0a_1x1", fa[1][0], (1, 1), 1, "same"), ("Conv2d_0b_3x3", fa[1][1], (3, 3), 1, "same"),
-             ("Conv2d_1a_3x3", fa[1][2], (3, 3), 2, "valid")]])
-        b17 = [[("Conv2d_1x1", 128, (1, 1))],
-               [("Conv2d_0a_1x1", 128, (1, 1)), ("Conv2d_0b_1x7", 128, (1, 7)), ("Conv2d_0c_7x1", 128, (7, 1))]]
+            x = g.block(f"block35/{i}", x, b35, up35, cfg["block35"]["scale"], True)
+        x = g.reduction("reduction_a", x, reduction_towers("reduction_a", cfg["reduction_a"]["filters"]))   # :262-307
+        b17, up17 = BLOCK_TOWERS["block17"]
         for i in range(cfg["block17"]["repeat"]):                                      # :441-443 ; relu hard-coded :158
-            x = g.block(f"block17/{i}", x, b17, 896, cfg["block17"]["scale"], True)
-        fb = cfg["reduction_b"]["filters"]                                              # :310-377
-        x = g.reduction("reduction_b", x, [
-            [("Conv2d_0a_1x1", fb[0][0], (1, 1), 1, "same"), ("Conv2d_1a_3x3", fb[0][1], (3, 3), 2, "valid")],
-            [("Conv2d_0a_1x1", fb[1][0], (1, 1), 1, "same"), ("Conv2d_1a_3x3", fb[1][1], (3, 3), 2, "valid")],
-            [("Conv2d_0a_1x1", fb[2][0], (1, 1), 1, "same"), ("Conv2d_0b_3x3", fb[2][1], (3, 3), 1, "same"),
-             ("Conv2d_1a_3x3", fb[2][2], (3, 3), 2, "valid")]])
-        b8 = [[("Conv2d_1x1", 192, (1, 1))],
-              [("Conv2d_0a_1x1", 192, (1, 1)), ("Conv2d_0b_1x3", 192, (1, 3)), ("Conv2d_0c_3x1", 192, (3, 1))]]
+            x = g.block(f"block17/{i}", x, b17, up17, cfg["block17"]["scale"], True)
+        x = g.reduction("reduction_b", x, reduction_towers("reduction_b", cfg["reduction_b"]["filters"]))   # :310-377
+        b8, up8 = BLOCK_TOWERS["block8"]
         for i in range(cfg["block8_1"]["repeat"]):                                     # :449-451 ; activation from config :213
-            x = g.block(f"block8/{i}", x, b8, 1792, cfg["block8_1"]["scale"], bool(cfg["block8_1"]["activation"]))
-        x = g.block("block8_2", x, b8, 1792, cfg["block8_2"]["scale"], bool(cfg["block8_2"]["activation"]))  # :453
+            x = g.block(f"block8/{i}", x, b8, up8, cfg["block8_1"]["scale"], bool(cfg["block8_1"]["activation"]))
+        x = g.block("block8_2", x, b8, up8, cfg["block8_2"]["scale"], bool(cfg["block8_2"]["activation"]))  # :453
         return g.head(x, self.E)                                                         # :459-468
 
     def _declare(self):
@@ -276,7 +290,8 @@ class Network:
     def _bn_prefix(L: Layer) -> str:
         return "features/bn" if L.name == "features/logits" else L.name + "/bn"
 
-    def load_keras_params(self, params: Dict[str, torch.Tensor]):
+    def _flat(self, params: Dict[str, torch.Tensor], with_stats: bool):
+        """Engine-keyed Keras-layout tensors -> the flat fp32 layout [kernels OHWI | pad | betas | biases] (+ moving statistics)."""
         P = torch.zeros(self.n_params, dtype=torch.float32)
         mean = torch.zeros(self.CB)
         var = torch.ones(self.CB)
@@ -296,17 +311,57 @@ class Network:
             if L.has_bn:
                 pre = self._bn_prefix(L)
                 P[self.beta_base + L.bn_off:self.beta_base + L.bn_off + L.cout] = torch.as_tensor(params[pre + "/beta"])
-                mean[L.bn_off:L.bn_off + L.cout] = torch.as_tensor(params[pre + "/moving_mean"])
-                var[L.bn_off:L.bn_off + L.cout] = torch.as_tensor(params[pre + "/moving_variance"])
+                if with_stats:
+                    mean[L.bn_off:L.bn_off + L.cout] = torch.as_tensor(params[pre + "/moving_mean"])
+                    var[L.bn_off:L.bn_off + L.cout] = torch.as_tensor(params[pre + "/moving_variance"])
+        return P, mean, var
+
+    def flat_from_keras(self, params: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Per-variable tensors (engine keys, Keras layouts; no moving statistics) -> one flat buffer laid out like ``P``
+        (gradients, Adam slots)."""
+        return self._flat(params, with_stats=False)[0].to(self.device)
+
+    def load_keras_params(self, params: Dict[str, torch.Tensor]):
+        """``params``: Keras-layout tensors keyed by Keras variable names (keras_names.py: the names and order the reference's
+        declaration produces) or by the engine's ``<layer>/kernel`` keys; matched by name."""
+        from . import keras_names
+        params = keras_names.from_keras(params, self.layers, int(self.cfg["block8_1"]["repeat"]))
+        P, mean, var = self._flat(params, with_stats=True)
         self.P.copy_(P)
         self.S_mean.copy_(mean)
         self.S_var.copy_(var)
         self.folded_valid = False
         self.refresh_packs()
 
-    def export_keras_params(self) -> "OrderedDict[str, torch.Tensor]":
+    def keras_variables(self, moving_stats: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> "OrderedDict[str, torch.Tensor]":
+        """``model.weights`` of the reference model: Keras variable names, Keras layouts, Keras order (keras_names.py)."""
+        from . import keras_names
+        return keras_names.to_keras(self.export_keras_params(moving_stats), self.layers, int(self.cfg["block8_1"]["repeat"]))
+
+    def export_folded_params(self) -> "OrderedDict[str, torch.Tensor]":
+        """BN-folded inference weights as facenet/tfutils.py:229-258 (export_h5) writes them: per layer ``<name>/weights`` =
+        kernel * 1/sqrt(moving_variance + eps) (HWIO) and ``<name>/biases`` = beta - moving_mean * scale, or the layer's own
+        bias.  Read back from the device packs the inference kernels use (fn_fold_bn), so this is what actually runs."""
+        self.refresh_folded(self.stream(), force=True)
+        torch.cuda.synchronize(self.device)
+        W = self.W_infer.float().cpu()
+        fb = self.fold_bias.cpu()
         P = self.P.detach().cpu()
-        mean, var = self.S_mean.cpu(), self.S_var.cpu()
+        out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        for L in self.layers.values():
+            w = W[L.w_off:L.w_off + L.numel].reshape(L.cout, L.kh, L.kw, L.cin)[:L.cout_real, ..., :L.cin_real]
+            out[L.name + "/weights"] = (w.reshape(L.cout_real, L.cin_real).t() if L.dense else w.permute(1, 2, 3, 0)).contiguous()
+            if L.has_bn:
+                out[L.name + "/biases"] = fb[L.bn_off:L.bn_off + L.cout].clone()
+            elif L.has_bias:
+                out[L.name + "/biases"] = P[L.bias_off:L.bias_off + L.cout_real].clone()
+        return out
+
+    def export_keras_params(self, moving_stats: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> "OrderedDict[str, torch.Tensor]":
+        """Keras-layout tensors under the engine's keys.  ``moving_stats``: (mean, var) to export instead of this replica's
+        (data parallelism: the cross-replica average, Trainer.averaged_moving_stats)."""
+        P = self.P.detach().cpu()
+        mean, var = (self.S_mean.cpu(), self.S_var.cpu()) if moving_stats is None else (moving_stats[0].cpu(), moving_stats[1].cpu())
         out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         for L in self.layers.values():
             w = P[L.w_off:L.w_off + L.numel].reshape(L.cout, L.kh, L.kw, L.cin)[:L.cout_real, ..., :L.cin_real]
@@ -374,6 +429,32 @@ class Network:
         return g
 
 
+class BlockNetwork(Network):
+    """ONE residual or reduction block (Block35 / Block17 / Block8 / ReductionA / ReductionB, inception_resnet_v1.py:83-377) on
+    a [N,H,W,C] low-precision feature map, lowered by the same engine code as the full network.  Used by the per-block
+    forward + backward parity tests ("block" level): ``plan.bufs['trunk']`` is the input (``.act`` in,
+    ``.grad`` out), ``plan.embedding`` the block output (``.act`` out, ``.grad`` in)."""
+
+    def __init__(self, kind: str, H: int, W: int, C: int, scale: float = 0.17, relu: bool = True, filters=None, **kw):
+        if kind not in BLOCK_TOWERS and kind not in ("reduction_a", "reduction_b"):
+            raise ValueError(f"unknown block kind {kind!r}")
+        self._blk = (kind, H, W, C, float(scale), bool(relu), filters)
+        super().__init__(embedding_size=8, **kw)
+
+    def _topology(self, g: "Lowering"):
+        kind, H, W, C, scale, relu, filters = self._blk
+        x = g.feature_input(H, W, C)
+        if kind in BLOCK_TOWERS:
+            towers, up = BLOCK_TOWERS[kind]
+            if up != C:
+                raise ValueError(f"{kind} expects {up} input channels, got {C}")
+            return g.block(kind, x, towers, up, scale, relu)
+        return g.reduction(kind, x, reduction_towers(kind, filters or DEFAULT_CONFIG[kind]["filters"]))
+
+    def _bn_prefix(self, L: Layer) -> str:
+        return L.name + "/bn"
+
+
 # ------------------------------------------------------------------------------------------------
 # lowering: topology -> buffers + forward records -> launch lists
 # ------------------------------------------------------------------------------------------------
@@ -427,6 +508,13 @@ class Lowering:
         self.images = None if self.declare else torch.zeros(self.N, H, W, 3, dtype=torch.uint8, device=self.net.device)
         self.norm_work = None if self.declare else torch.zeros(4 * self.N, dtype=torch.float32, device=self.net.device)
         b = self.buf("input", H, W, 8)
+        return b.full()
+
+    def feature_input(self, H: int, W: int, Cc: int) -> Slice:
+        """A low-precision NHWC feature map as the plan's input (BlockNetwork): no image normalisation, and -- unlike the image
+        input -- it receives a data gradient."""
+        self.images = None
+        b = self.buf("trunk", H, W, Cc)
         return b.full()
 
     @staticmethod
@@ -515,8 +603,10 @@ class Lowering:
     def head(self, x: Slice, E: int) -> Slice:
         """features (:459-468): AvgPool2D([3,3]) valid (stride = pool) -> Flatten -> Dense(no bias) -> BN."""
         H, W = x.buf.H, x.buf.W
-        if (H // 3, W // 3) != (1, 1):
-            raise ValueError(f"head expects a 3x3..5x5 final map (image size 160), got {H}x{W}")  # Flatten ambiguity, hazard 11
+        if (H, W) != (3, 3):
+            # AvgPool2D([3,3], 'valid') pools the top-left 3x3 window only and Flatten of a larger pooled map has a layout of
+            # its own (hazard 11): the whole-map average of fn_avgpool_* is the reference's result for 3x3 maps exactly
+            raise ValueError(f"head expects a 3x3 final map (image sizes 139..170; the reference uses 160), got {H}x{W}")
         pooled = self.buf("features/avgpool", 1, 1, x.C)
         self.readers[x.buf.name] = self.readers.get(x.buf.name, 0) + 1
         self.recs.append(Rec("avgpool", None, x, pooled.full()))
@@ -592,10 +682,11 @@ class Lowering:
             self._find_virtual()
             self.fin_reps = torch.zeros(CB, dtype=torch.int32)
             self.fin_count = torch.ones(CB, dtype=torch.int32)
-        inp = self.bufs["input"]
-        self._emit(self.fwd, "image_normalize", lib.fn_image_normalize, _ptr(self.images), _ptr(inp.act), _ptr(self.norm_work),
-                   N, self.images.shape[1] * self.images.shape[2], net.normalization, self.dt,
-                   r=[region(self.images)], w=[self._ra(inp.full()), region(self.norm_work)])
+        inp = self.bufs.get("input")
+        if inp is not None:
+            self._emit(self.fwd, "image_normalize", lib.fn_image_normalize, _ptr(self.images), _ptr(inp.act), _ptr(self.norm_work),
+                       N, self.images.shape[1] * self.images.shape[2], net.normalization, self.dt,
+                       r=[region(self.images)], w=[self._ra(inp.full()), region(self.norm_work)])
         for r in self.recs:
             getattr(self, "_fwd_" + r.kind)(r)
         if self.training and self.virtual:

@@ -133,7 +133,8 @@ class InceptionResnetV1:
         self.network.load_keras_params(params)
 
     def save_weights(self, path):
-        np.savez(path, **{k: v.numpy() for k, v in self.network.export_keras_params().items()})
+        """``.npz`` keyed by the reference model's Keras variable names, in ``model.weights`` order (keras_names.py)."""
+        np.savez(path, **{k: v.numpy() for k, v in self.network.keras_variables().items()})
 
     def load_weights(self, path):
         with np.load(path, allow_pickle=False) as z:

@@ -48,14 +48,6 @@ def pairwise_similarities(xa, xb=None, metric: int = 0, atol: float = 1.e-5, dev
 # Face-to-face validation (facenet/statistics.py:82-331) on the GPU.  Same class names, properties and report text as
 # the reference; the O(classes^2 x thresholds) NumPy loops run as ONE launch of fn_confidence_counts per matrix.
 # ------------------------------------------------------------------------------------------------------------------
-def mean(x):
-    return np.mean(np.array(x))
-
-
-def std(x):
-    return np.std(np.array(x))
-
-
 class SimilarityCalculator:
     """statistics.py:82-108.  Holds the embeddings grouped by class on the device (rows sorted by label)."""
 
@@ -89,8 +81,18 @@ class SimilarityCalculator:
         return sims, weight
 
 
+def _ratio_or_one(num, den):
+    """num / den element-wise, 1 where den == 0 (an empty positive or negative set scores perfectly, statistics.py:144-168)."""
+    num, den = np.asarray(num, dtype=np.float64), np.asarray(den, dtype=np.float64)
+    return np.divide(num, den, out=np.ones_like(den), where=den > 0)
+
+
 class ConfidenceMatrix:
-    """statistics.py:111-175: tp / tn / fp / fn per threshold with class-balanced weights, and the derived rates."""
+    """Interface of statistics.py:111-175 (attributes tp / tn / fp / fn / threshold, the six rate properties).  The
+    class-balanced counts for ALL thresholds come from one fn_confidence_counts launch into ``counts`` [4, T]; every rate is
+    a ratio of two rows of it."""
+
+    _ROWS = {"tp": 0, "tn": 1, "fp": 2, "fn": 3}
 
     def __init__(self, calculator: SimilarityCalculator, threshold, atol: float = 1.e-5):
         lib = _lib.load()
@@ -106,41 +108,35 @@ class ConfidenceMatrix:
         st = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(lib.fn_confidence_counts(_ptr(calculator.emb), _ptr(calculator._cls), calculator.nrof_classes, E, _ptr(t_dev), thr.size,
                                             calculator.metric, _ptr(out), _ptr(rng), st), "confidence_counts")
-        o = out.cpu().numpy().reshape(4, thr.size)
+        self.counts = out.cpu().numpy().reshape(4, thr.size)
         lo, hi = (_decode_ord(v) for v in rng.cpu().tolist())
-        if hi >= lo:                                   # at least one pair was evaluated
-            lim = 1 + atol
-            if lo < -lim or hi > lim:                  # statistics.py:40-42
-                raise ValueError("\nembeddings must be normalized to 1, range {} {}".format(lo, hi))
-        self.tp, self.tn, self.fp, self.fn = o[0].copy(), o[1].copy(), o[2].copy(), o[3].copy()
+        if hi >= lo and (lo < -(1 + atol) or hi > 1 + atol):   # some pair was evaluated and left [-1, 1]: statistics.py:40-42
+            raise ValueError("\nembeddings must be normalized to 1, range {} {}".format(lo, hi))
+
+    def __getattr__(self, name):        # tp, tn, fp, fn are views of the count table
+        row = ConfidenceMatrix._ROWS.get(name)
+        if row is None or "counts" not in self.__dict__:
+            raise AttributeError(name)
+        return self.counts[row]
 
     @property
     def accuracy(self):
-        return (self.tp + self.tn) / (self.tp + self.fp + self.tn + self.fn)
+        return (self.tp + self.tn) / self.counts.sum(axis=0)
 
     @property
     def precision(self):
-        i = (self.tp + self.fp) > 0
-        precision = np.ones(self.threshold.size)
-        precision[i] = self.tp[i] / (self.tp[i] + self.fp[i])
-        return precision
+        return _ratio_or_one(self.tp, self.tp + self.fp)
 
     @property
-    def tp_rates(self):
-        i = (self.tp + self.fn) > 0
-        tp_rates = np.ones(self.threshold.size)
-        tp_rates[i] = self.tp[i] / (self.tp[i] + self.fn[i])
-        return tp_rates
+    def tp_rates(self):      # sensitivity / recall
+        return _ratio_or_one(self.tp, self.tp + self.fn)
 
     @property
-    def tn_rates(self):
-        i = (self.tn + self.fp) > 0
-        tn_rates = np.ones(self.threshold.size)
-        tn_rates[i] = self.tn[i] / (self.tn[i] + self.fp[i])
-        return tn_rates
+    def tn_rates(self):      # specificity
+        return _ratio_or_one(self.tn, self.tn + self.fp)
 
     @property
-    def fp_rates(self):
+    def fp_rates(self):      # false alarm rate
         return 1 - self.tn_rates
 
     @property
@@ -164,111 +160,113 @@ def far_threshold_slinear(fp_rates, thresholds, far_target):
     return thr[j] + (far_target - fp[j]) / (fp[j + 1] - fp[j]) * (thr[j + 1] - thr[j])
 
 
+_SCORED = ("accuracy", "precision", "tp_rates", "tn_rates", "threshold")     # keys of Report.dict besides auc / eer
+_REPORT_LINES = (("Accuracy:  ", "accuracy"), ("Precision: ", "precision"), ("Sensitivity (TPR, 1-a type 1 error): ", "tp_rates"),
+                 ("Specificity (TNR, 1-b type 2 error): ", "tn_rates"), ("Threshold: ", "threshold"))
+
+
+def _roc_summary(fpr, tpr):
+    """(AUC, EER) of a ROC polyline; -1 where the reference's try/except leaves its default (statistics.py:212-222)."""
+    import sklearn.metrics
+    from scipy import interpolate
+    from scipy.optimize import brentq
+    auc = eer = -1
+    try:
+        auc = sklearn.metrics.auc(fpr, tpr)
+    except Exception:
+        pass
+    try:
+        roc = interpolate.interp1d(fpr, tpr)
+        eer = brentq(lambda x: 1. - x - roc(x), 0., 1.)
+    except Exception:
+        pass
+    return auc, eer
+
+
 class Report:
-    """statistics.py:178-234."""
+    """Interface of statistics.py:178-234 (criterion, conf_matrix_train / conf_matrix_test, append_fold, dict, the report
+    text).  The dictionary is computed from stacked [folds, ...] arrays; the text is rendered from a line table."""
 
     def __init__(self, criterion=None):
         self.criterion = criterion
         self.conf_matrix_train = []
         self.conf_matrix_test = []
 
-    def __repr__(self):
-        dct = self.dict
-        info = self.criterion + '\n'
-        info += ('Area under curve (AUC): {:1.5f}\n'.format(dct['auc']) +
-                 'Equal error rate (EER): {:1.5f}\n'.format(dct['eer']) + '\n')
-        info += ('Accuracy:  {:2.5f}+-{:2.5f}\n'.format(dct['accuracy'], dct['accuracy_std']) +
-                 'Precision: {:2.5f}+-{:2.5f}\n'.format(dct['precision'], std(dct['precision_std'])) +
-                 'Sensitivity (TPR, 1-a type 1 error): {:2.5f}+-{:2.5f}\n'.format(dct['tp_rates'], dct['tp_rates_std']) +
-                 'Specificity (TNR, 1-b type 2 error): {:2.5f}+-{:2.5f}\n'.format(dct['tn_rates'], dct['tn_rates_std']) +
-                 'Threshold: {:2.5f}+-{:2.5f}\n'.format(dct['threshold'], dct['threshold_std']) + '\n')
-        return info
-
     def append_fold(self, name, conf_matrix):
-        if name == 'train':
-            self.conf_matrix_train.append(conf_matrix)
-        else:
-            self.conf_matrix_test.append(conf_matrix)
+        (self.conf_matrix_train if name == 'train' else self.conf_matrix_test).append(conf_matrix)
 
     @property
     def dict(self):
-        import sklearn.metrics
-        from scipy import interpolate
-        from scipy.optimize import brentq
-        tp_rates = np.mean(np.array([m.tp_rates for m in self.conf_matrix_train]), axis=0)
-        tn_rates = np.mean(np.array([m.tn_rates for m in self.conf_matrix_train]), axis=0)
-        dct = {'auc': -1, 'eer': -1}
-        try:
-            dct['auc'] = sklearn.metrics.auc(1 - tn_rates, tp_rates)
-        except Exception:
-            pass
-        try:
-            dct['eer'] = brentq(lambda x: 1. - x - interpolate.interp1d(1 - tn_rates, tp_rates)(x), 0., 1.)
-        except Exception:
-            pass
+        train = self.conf_matrix_train
+        tpr = np.stack([m.tp_rates for m in train]).mean(axis=0)
+        fpr = 1 - np.stack([m.tn_rates for m in train]).mean(axis=0)
+        auc, eer = _roc_summary(fpr, tpr)
+        out = {'auc': auc, 'eer': eer}
+        for key in _SCORED:
+            per_fold = np.array([getattr(m, key) for m in self.conf_matrix_test])
+            out[key] = per_fold.mean()
+            out[key + '_std'] = per_fold.std()
+        return out
 
-        def get(name):
-            return [m.__getattribute__(name) for m in self.conf_matrix_test]
-
-        for key in ('accuracy', 'precision', 'tp_rates', 'tn_rates', 'threshold'):
-            x = get(key)
-            dct[key] = np.mean(x)
-            dct[key + '_std'] = np.std(x)
-        return dct
+    def __repr__(self):
+        d = self.dict
+        head = '{}\nArea under curve (AUC): {:1.5f}\nEqual error rate (EER): {:1.5f}\n\n'.format(self.criterion, d['auc'], d['eer'])
+        # the reference prints std(precision_std) -- the spread of a scalar, i.e. 0 -- on the precision line (statistics.py:196)
+        spread = {k: (0.0 if k == 'precision' else d[k + '_std']) for _, k in _REPORT_LINES}
+        body = ''.join('{}{:2.5f}+-{:2.5f}\n'.format(label, d[k], spread[k]) for label, k in _REPORT_LINES)
+        return head + body + '\n'
 
 
 class FaceToFaceValidation:
-    """statistics.py:237-331: k-fold (KFold(shuffle=True, random_state=0) over image indices) max-accuracy and FAR-target
-    thresholds on the training folds, scored on the test folds.  ``config``: .metric, .nrof_folds, .far_target."""
+    """Interface of statistics.py:237-331: k-fold (KFold(shuffle=True, random_state=0) over image indices); per fold the
+    max-accuracy and the FAR-target thresholds are chosen on the training part and scored on the held-out part.
+    ``config``: .metric, .nrof_folds, .far_target.  Embeddings stay on the device; every matrix is one kernel launch."""
+
+    _UPPER = {0: 4, 1: np.pi}       # largest possible similarity value per metric (statistics.py:253-258)
 
     def __init__(self, embeddings, labels, config, device: str = "cuda"):
         import time
-        self.elapsed_time = time.monotonic()
+        t0 = time.monotonic()
+        self.config = config
+        if config.metric not in self._UPPER:
+            raise ValueError('Undefined similarity metric {}'.format(config.metric))
         self.labels = np.asarray(labels)
         emb = embeddings if torch.is_tensor(embeddings) else torch.as_tensor(np.asarray(embeddings))
         self.embeddings = emb.to(device=device, dtype=torch.float32)
-        assert (self.embeddings.shape[0] == len(self.labels))
-        self.config = config
-        self.reports = None
-        if self.config.metric == 0:
-            upper_threshold = 4
-        elif self.config.metric == 1:
-            upper_threshold = np.pi
-        else:
-            raise ValueError('Undefined similarity metric {}'.format(self.config.metric))
-        self.thresholds = np.linspace(0, upper_threshold, 100)
+        assert self.embeddings.shape[0] == len(self.labels)
+        self.thresholds = np.linspace(0, self._UPPER[config.metric], 100)
+        self.reports = (Report(criterion='MaximumAccuracy'),
+                        Report(criterion='FalseAlarmRate(FAR = {})'.format(config.far_target)))
         self._evaluate()
+        self.elapsed_time = time.monotonic() - t0
 
-    def __repr__(self):
-        info = (f'{self.__class__.__name__}\n' + f'metric: {self.config.metric}\n\n')
-        for r in self.reports:
-            info += str(r)
-        info += f'elapsed_time: {self.elapsed_time}\n'
-        return info
+    def _calculator(self, subset) -> SimilarityCalculator:
+        dev = self.embeddings.device
+        return SimilarityCalculator(self.embeddings[torch.as_tensor(subset, device=dev)], self.labels[subset],
+                                    metric=self.config.metric, device=str(dev))
+
+    def _fold_thresholds(self, matrix: ConfidenceMatrix):
+        """(threshold of maximal accuracy, threshold where the false-alarm rate reaches far_target or 0)."""
+        best = self.thresholds[int(np.argmax(matrix.accuracy))]
+        fpr = matrix.fp_rates
+        far = far_threshold_slinear(fpr, self.thresholds, self.config.far_target) if fpr.max() >= self.config.far_target else 0
+        return best, far
 
     def _evaluate(self):
-        import time
         from sklearn.model_selection import KFold
-        k_fold = KFold(n_splits=self.config.nrof_folds, shuffle=True, random_state=0)
-        indices = np.arange(len(self.labels))
-        self.reports = (Report(criterion='MaximumAccuracy'),
-                        Report(criterion='FalseAlarmRate(FAR = {})'.format(self.config.far_target)))
-        dev = self.embeddings.device
-        for fold_idx, (train_set, test_set) in enumerate(k_fold.split(indices)):
-            calculator = SimilarityCalculator(self.embeddings[torch.as_tensor(train_set, device=dev)], self.labels[train_set],
-                                              metric=self.config.metric, device=str(dev))
-            matrix = ConfidenceMatrix(calculator, self.thresholds)
-            for i in range(len(self.reports)):
-                self.reports[i].append_fold('train', matrix)
-            accuracy_threshold = self.thresholds[np.argmax(matrix.accuracy)]
-            far_threshold = 0
-            if np.max(matrix.fp_rates) >= self.config.far_target:
-                far_threshold = far_threshold_slinear(matrix.fp_rates, self.thresholds, self.config.far_target)
-            calculator = SimilarityCalculator(self.embeddings[torch.as_tensor(test_set, device=dev)], self.labels[test_set],
-                                              metric=self.config.metric, device=str(dev))
-            self.reports[0].append_fold('test', ConfidenceMatrix(calculator, accuracy_threshold))
-            self.reports[1].append_fold('test', ConfidenceMatrix(calculator, far_threshold))
-        self.elapsed_time = time.monotonic() - self.elapsed_time
+        folds = KFold(n_splits=self.config.nrof_folds, shuffle=True, random_state=0)
+        for train_set, test_set in folds.split(np.arange(len(self.labels))):
+            fitted = ConfidenceMatrix(self._calculator(train_set), self.thresholds)
+            held_out = self._calculator(test_set)
+            for report, thr in zip(self.reports, self._fold_thresholds(fitted)):
+                report.append_fold('train', fitted)
+                report.append_fold('test', ConfidenceMatrix(held_out, thr))
+
+    def _text(self, header: str, footer: str = '') -> str:
+        return header + 'metric: {}\n\n'.format(self.config.metric) + ''.join(str(r) for r in self.reports) + footer
+
+    def __repr__(self):
+        return self._text(f'{self.__class__.__name__}\n', f'elapsed_time: {self.elapsed_time}\n')
 
     @property
     def dict(self):
@@ -277,10 +275,5 @@ class FaceToFaceValidation:
     def write_report(self, file):
         import datetime
         from pathlib import Path
-        file = Path(file).expanduser()
-        with file.open('at') as f:
-            f.write(64 * '-' + '\n')
-            f.write('{} {}\n'.format(self.__class__.__name__, datetime.datetime.now()))
-            f.write('metric: {}\n\n'.format(self.config.metric))
-            for r in self.reports:
-                f.write(str(r))
+        with Path(file).expanduser().open('at') as f:
+            f.write(self._text(64 * '-' + '\n' + '{} {}\n'.format(self.__class__.__name__, datetime.datetime.now())))

@@ -18,6 +18,7 @@ import json
 import os
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib, parallel
@@ -237,6 +238,12 @@ class Trainer:
         # hyper = {lr, beta1^t, beta2^t, grad_scale}; lives on device so HIP-graph replays see LR changes
         self.hyper = torch.tensor([lr, 1.0, 1.0, 1.0 / world_size], dtype=torch.float32, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        if world_size > 1:
+            # MirroredStrategy creates every replica from the SAME variables (apps/train_softmax_tf2_gpus.py:49-67): rank 0's
+            # parameters and moving statistics win, whatever seed or file the other ranks were built from
+            parallel.broadcast_parameters([net.P, net.S_mean, net.S_var], src=0, group=process_group)
+            net.folded_valid = False
+            net.refresh_packs()
         self.plan: Lowering = net.plan(batch, training=True)
         self.demb = torch.zeros(batch, E, dtype=torch.float32, device=dev)
         self.dt = _lib.dtype_code(net.train_dtype)
@@ -396,8 +403,18 @@ class Trainer:
         if self.n_streams > 2:
             self.n_streams = 2
             self._build_segments()
+        # The warm-up below is a full training step on whatever the image buffer holds.  Training state is snapshotted and
+        # restored around it, so capture() followed by n steps equals n eager steps (Adam's t, the moving statistics and the
+        # parameters are untouched; the reference's fit() has no uncounted step either).
+        net = self.net
+        saved = [t.clone() for t in (net.P, net.S_mean, net.S_var, self.M, self.V, self.hyper)]
         self.step_eager()           # warm-up: first-call attribute set-up, allocator
-        torch.cuda.synchronize(self.net.device)
+        torch.cuda.synchronize(net.device)
+        for t, s in zip((net.P, net.S_mean, net.S_var, self.M, self.V, self.hyper), saved):
+            t.copy_(s)
+        net.folded_valid = False
+        net.refresh_packs()
+        torch.cuda.synchronize(net.device)
         runner = GraphRunner(self.net.device)
         graphs, keep = [], []
         for (sched, _) in self.segments:
@@ -419,7 +436,72 @@ class Trainer:
     def set_images(self, images: torch.Tensor, labels: Optional[torch.Tensor] = None):
         self.plan.images.copy_(images.to(self.net.device, non_blocking=True))
         if labels is not None:
+            if self.loss_kind != "softmax":
+                raise ValueError("labels are only used by the softmax loss")
+            labels = torch.as_tensor(labels)
+            nc = self.net.layers["classifier/logits"].cout_real
+            if labels.numel() != self.N or int(labels.min()) < 0 or int(labels.max()) >= nc:
+                # TF's sparse softmax cross-entropy rejects out-of-range class indices; the kernel indexes logits[label]
+                raise ValueError(f"labels must be {self.N} class indices in [0, {nc}), got range [{int(labels.min())}, {int(labels.max())}]")
             self.labels.copy_(labels.to(device=self.net.device, dtype=torch.int32))
+
+    # ---- checkpoints (apps/train_softmax.py:68-78,105; SURVEY.md section 5: optimiser state) -----------------------------
+    def averaged_moving_stats(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """BatchNorm moving statistics as MirroredStrategy reads them: every replica keeps its own (per-replica batch
+        statistics), a read or save aggregates them with MEAN (apps/train_softmax_tf2_gpus.py:49).  Collective:
+        every rank must call it."""
+        mean, var = self.net.S_mean.clone(), self.net.S_var.clone()
+        if self.world > 1:
+            import torch.distributed as dist
+            for t in (mean, var):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+                t.mul_(1.0 / self.world)
+        return mean, var
+
+    def state_dict(self, epoch: int = 0) -> "Dict[str, np.ndarray]":
+        """Model variables under their Keras names (replica-averaged moving statistics) + the Keras-Adam slots ``Adam/<var>/m``,
+        ``Adam/<var>/v``, ``Adam/iter`` and the schedule position: everything ``fit`` needs to resume."""
+        from . import keras_names
+        net = self.net
+        rep = int(net.cfg["block8_1"]["repeat"])
+        out = {k: v.numpy() for k, v in net.keras_variables(self.averaged_moving_stats()).items()}
+        table = dict((i, k) for k, i in keras_names.keras_variable_table(net.layers, rep))
+        for slot, buf in (("m", self.M), ("v", self.V)):
+            for key, t in net.export_keras_grads(buf).items():
+                out[keras_names.optimizer_slot_names(table[key])[0 if slot == "m" else 1]] = t.numpy()
+        h = self.hyper.cpu().numpy()
+        # beta1^t -> t (hyper[1] is the running power the fused optimiser reads)
+        it = 0 if h[1] >= 1.0 else int(round(float(np.log(h[1]) / np.log(self.beta1))))
+        out["Adam/iter:0"] = np.asarray(it, dtype=np.int64)
+        out["Adam/learning_rate:0"] = np.asarray(h[0], dtype=np.float32)
+        out["Adam/beta_powers"] = h[1:3].astype(np.float32)
+        out["epoch"] = np.asarray(int(epoch), dtype=np.int64)
+        return out
+
+    def save_checkpoint(self, path, epoch: int = 0):
+        sd = self.state_dict(epoch)          # collective when world > 1; rank 0 writes
+        if self.world == 1 or int(os.environ.get("RANK", "0")) == 0:
+            np.savez(path, **sd)
+
+    def load_checkpoint(self, path) -> int:
+        """Restore parameters, moving statistics and optimiser state; returns the stored epoch."""
+        from . import keras_names
+        net = self.net
+        with np.load(path, allow_pickle=False) as z:
+            sd = {k: z[k] for k in z.files}
+        net.load_keras_params({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items() if not k.startswith("Adam/") and k != "epoch"})
+        if "Adam/iter:0" in sd:
+            rep = int(net.cfg["block8_1"]["repeat"])
+            for slot, buf in ((0, self.M), (1, self.V)):
+                tmp = {}
+                for k, i in keras_names.keras_variable_table(net.layers, rep):
+                    if i.endswith(("/moving_mean", "/moving_variance")):
+                        continue
+                    tmp[i] = torch.from_numpy(sd[keras_names.optimizer_slot_names(k)[slot]])
+                buf.copy_(net.flat_from_keras(tmp))
+            self.hyper[0:1].fill_(float(sd["Adam/learning_rate:0"]))
+            self.hyper[1:3].copy_(torch.from_numpy(sd["Adam/beta_powers"]))
+        return int(sd.get("epoch", 0))
 
     def set_learning_rate(self, lr: float):
         self.hyper[0:1].fill_(float(lr))     # device write: visible to the next graph replay
@@ -437,6 +519,18 @@ class TripletMiner:
         self.net, self.n, self.T, self.alpha, self.seed, self.semi_hard = net, pool_size, nrof_triplets, alpha, seed, semi_hard
         dev = net.device
         self.n_streams = n_streams
+        lab = np.asarray(list(labels))
+        if lab.shape != (pool_size,):
+            raise ValueError(f"labels must have one entry per pool image ({pool_size}), got {lab.shape}")
+        _, counts = np.unique(lab, return_counts=True)
+        pairs = int((counts * (counts - 1) // 2).sum())
+        # every selected triplet needs its own anchor-positive pair and a negative of another identity: a pool that cannot
+        # supply them would leave triplet slots unwritten (the gather would reuse stale indices)
+        if len(counts) < 2 or pairs < nrof_triplets:
+            raise ValueError(f"the pool holds {len(counts)} identities and {pairs} anchor-positive pairs; {nrof_triplets} triplets need "
+                             f">= 2 identities and >= {nrof_triplets} pairs")
+        if pairs > 1 << 15:
+            raise ValueError(f"{pairs} anchor-positive pairs exceed the 32768 the on-device ranking handles; use more identities with fewer images each")
         self.plan = net.plan(pool_size, training=False)
         E = net.E
         self.emb = self.plan.embedding.buf.act.view(pool_size, E)

@@ -31,6 +31,9 @@ class QuantOracle(fo.Oracle):
         if training:
             dims = (0, 2, 3)
             mean, var = y.mean(dim=dims), y.var(dim=dims, unbiased=False)
+            mm, mv = self.p[prefix + "/bn/moving_mean"], self.p[prefix + "/bn/moving_variance"]
+            self.new_stats[prefix + "/bn/moving_mean"] = mm * fo.BN_MOMENTUM + mean.detach() * (1 - fo.BN_MOMENTUM)
+            self.new_stats[prefix + "/bn/moving_variance"] = mv * fo.BN_MOMENTUM + var.detach() * (1 - fo.BN_MOMENTUM)
         else:
             mean, var = self.p[prefix + "/bn/moving_mean"], self.p[prefix + "/bn/moving_variance"]
         yq = _q(y, self.dt)

@@ -1,0 +1,141 @@
+"""Block-level forward + backward parity ("block: Block35/17/8, ReductionA/B fwd+bwd vs CPU restatement").
+
+Each residual / reduction block of facenet/models/inception_resnet_v1.py:83-377 is lowered ALONE by the engine
+(engine.BlockNetwork: the same lowering code, the same kernels, the same fusions as in the full network) at batch >= 32 and
+compared with fp32 autograd on identically rounded operands: tests/quant_oracle.py rounds weights, raw convolution outputs,
+BN+ReLU outputs and the block output to the storage type at the points the HIP path stores them (straight-through
+gradients), everything else is PyTorch-CPU fp32.  Tolerances (relative L2): output 4e-3 / 1e-3, dX and every dW / dbeta / dbias
+1e-2 (bf16) and 2e-3 (f16).  PARITY UNPINNED by the reference (no vectors)."""
+import numpy as np
+import pytest
+import torch
+
+from facenet_amd.engine import BLOCK_TOWERS, BlockNetwork
+from oracle import facenet_oracle as fo
+from tests.quant_oracle import QuantOracle
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # kind, H, W, C, N, scale, relu
+    ("block35", 17, 17, 256, 32, 0.17, True),
+    ("block17", 8, 8, 896, 32, 0.10, True),
+    ("block8", 3, 3, 1792, 48, 0.2, True),
+    ("block8", 3, 3, 1792, 48, 1.0, False),      # the last Block8: scale 1, no activation (:453)
+    ("reduction_a", 17, 17, 256, 32, 0.0, True),
+    ("reduction_b", 8, 8, 896, 32, 0.0, True),
+]
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def _oracle_block(params, kind, x_nchw, scale, relu, dt):
+    o = QuantOracle(params, dt)
+    if kind in BLOCK_TOWERS:
+        blk = {"block35": fo.BLOCK35, "block17": fo.BLOCK17, "block8": fo.BLOCK8}[kind]
+        return o._block(x_nchw, kind, blk, scale, "relu" if relu else None, True), o
+    spec = fo.reduction_a_spec(fo.DEFAULT_CONFIG["reduction_a"]["filters"]) if kind == "reduction_a" else \
+        fo.reduction_b_spec(fo.DEFAULT_CONFIG["reduction_b"]["filters"])
+    return o._reduction(x_nchw, kind, spec, True), o
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kind,H,W,C,N,scale,relu", CASES)
+def test_block_forward_backward_against_rounded_autograd(kind, H, W, C, N, scale, relu, dt):
+    net = BlockNetwork(kind, H, W, C, scale=scale, relu=relu, device="cuda:0", train_dtype=dt, seed=11)
+    # non-trivial beta / bias so that their gradients and the ReLU masks are exercised
+    g = torch.Generator().manual_seed(5)
+    params = net.export_keras_params()
+    for k in params:
+        if k.endswith("/beta") or k.endswith("/bias"):
+            params[k] = 0.1 * torch.randn(params[k].shape, generator=g)
+    net.load_keras_params(params)
+    trainable = [k for k in params if not k.endswith(("/moving_mean", "/moving_variance"))]
+    plan = net.plan(N, training=True)
+    net.G = torch.zeros(net.n_params, dtype=torch.float32, device=net.device)
+    # the trunk is the output of a ReLU in the real network: non-negative, O(1)
+    x = torch.relu(torch.randn(N, H, W, C, generator=g) + 0.3).to(dt)
+    trunk, out = plan.bufs["trunk"], plan.embedding.buf
+    trunk.act.copy_(x)
+    st = net.stream()
+    plan.ws.zero_(); plan.ws_b.zero_()
+    plan.run_ops(plan.fwd, st)
+    dout = (0.05 * torch.randn(N, out.H, out.W, out.C, generator=g)).to(dt)
+    out.grad.copy_(dout)
+    plan.build_backward(None)
+    plan.run_ops(plan.bwd, st)
+    torch.cuda.synchronize()
+
+    # reference: fp32 autograd, operands rounded where the HIP path stores them
+    for k in trainable:
+        params[k].requires_grad_(True)
+    xr = x.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    y_ref, orc = _oracle_block(params, kind, xr, scale, relu, dt)
+    y_ref.backward(dout.float().permute(0, 3, 1, 2))
+    y_ref = y_ref.detach().permute(0, 2, 3, 1)
+    dx_ref = xr.grad.permute(0, 2, 3, 1)
+
+    tol_y, tol_g = (1e-3, 2e-3) if dt == torch.float16 else (4e-3, 1e-2)
+    e_y = _rel(out.act.float().cpu(), y_ref)
+    e_dx = _rel(trunk.grad.float().cpu(), dx_ref)
+    mine = net.export_keras_grads(net.G)
+    errs = {k: _rel(mine[k], params[k].grad) for k in trainable if params[k].grad is not None and params[k].grad.norm() > 1e-6}
+    worst = max(errs, key=errs.get)
+    print(f"{kind} N={N} {dt}: out {e_y:.2e}  dX {e_dx:.2e}  worst dW {worst} {errs[worst]:.2e}  median {np.median(list(errs.values())):.2e}")
+    assert e_y < tol_y
+    assert e_dx < tol_g
+    assert len(errs) >= len(net.layers)          # every kernel has a gradient
+    for k, e in errs.items():
+        assert e < tol_g, (k, e)
+    # moving statistics: momentum 0.99, biased batch variance (hazard 3), from the un-rounded accumulators
+    new = net.export_keras_params()
+    assert orc.new_stats, "the oracle recorded no moving statistics"
+    for k, v in orc.new_stats.items():
+        assert torch.allclose(new[k], v, rtol=2e-2, atol=2e-3), k
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_batchnorm_statistics_with_mean_far_from_zero(dt, lib):
+    """Keras' non-fused BatchNormalization (inception_resnet_v1.py:56-63) takes the variance as mean((x - mean)^2); the
+    convolution epilogue accumulates sum and sum of squares.  Channels with |mean| = 50 std (and 200 std) must still give
+    the two-pass statistics: rstd within 1e-3 relative, shift within 2e-2 absolute of an fp64 two-pass reference."""
+    import ctypes as C
+    from facenet_amd import _lib
+    from tests.util import conv_desc, ptr, stream
+    code = _lib.dtype_code(dt)
+    N, H, W, Cc = 32, 35, 35, 64
+    M = N * H * W
+    g = torch.Generator().manual_seed(0)
+    ratio = torch.tensor([50.0] * 32 + [200.0] * 16 + [0.0] * 16)
+    std = torch.tensor([1.0] * 16 + [0.05] * 16 + [0.25] * 32)
+    x = (torch.randn(M, Cc, generator=g) * std + ratio * std).to(dt)          # what the kernel reads (already rounded)
+    w = torch.eye(Cc).to(dt)                                                    # 1x1 identity: y == x exactly
+    dev = "cuda:0"
+    xd, wd = x.to(dev), w.to(dev)
+    y = torch.zeros(M, Cc, dtype=dt, device=dev)
+    z = torch.zeros(M, Cc, dtype=dt, device=dev)
+    reps = 16
+    ws = torch.zeros(reps * 2 * Cc, dtype=torch.float32, device=dev)
+    d = conv_desc(N, H, W, Cc, Cc, 1, 1, 1, 0, 0, code)
+    d.x, d.w, d.y = ptr(xd), ptr(wd), ptr(y)
+    d.stats, d.stats_sq_off, d.stats_replicas, d.stats_rep_stride = ptr(ws), Cc, reps, 2 * Cc
+    _lib.check(lib.fn_conv2d_fwd(C.byref(d), stream()), "conv_fwd")
+    beta = torch.zeros(Cc, device=dev)
+    sc, sh = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    mm, mv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+    _lib.check(lib.fn_bn_relu_train_fwd(ptr(y), Cc, ptr(z), Cc, M, Cc, ptr(ws), Cc, reps, 2 * Cc, ptr(beta), ptr(sc), ptr(sh), ptr(mm), ptr(mv),
+                                        0.99, 1e-3, 0, code, stream()), "bn_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), x)
+    x64 = x.double()
+    mean = x64.mean(0)
+    var = ((x64 - mean) ** 2).mean(0)
+    rstd = 1.0 / torch.sqrt(var + 1e-3)
+    e_rstd = ((sc.cpu().double() - rstd).abs() / rstd).max().item()
+    e_shift = (sh.cpu().double() - (-mean * rstd)).abs().max().item()
+    e_mv = ((mv.cpu().double() - (0.99 + 0.01 * var)).abs() / (0.99 + 0.01 * var)).max().item()
+    print(f"{dt}: rstd rel err {e_rstd:.2e}, shift abs err {e_shift:.2e} (|shift| up to {(mean * rstd).abs().max():.1f}), moving var rel err {e_mv:.2e}")
+    assert e_rstd < 1e-3
+    assert e_shift < 2e-2
+    assert e_mv < 1e-3

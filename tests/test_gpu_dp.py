@@ -88,5 +88,73 @@ def test_two_replicas_match_manual_gradient_average(use_graph):
     cos_g = float(np.dot(gsum, res[0][2]) / (np.linalg.norm(gsum) * np.linalg.norm(res[0][2])))
     cos_u = float(np.dot(upd_ref, upd_dp) / (np.linalg.norm(upd_ref) * np.linalg.norm(upd_dp)))
     print(f"graph={use_graph}: cosine(summed grads) {cos_g:.4f}, cosine(param update) {cos_u:.4f}, |update| {np.linalg.norm(upd_dp):.4f} vs {np.linalg.norm(upd_ref):.4f}")
-    assert cos_g > 0.97 and cos_u > 0.97       # limited by run-to-run training noise (fp32 atomics + storage rounding)
+    # noise floor: the single-process emulation repeated -- fp32 atomics make two runs of the SAME step differ (DESIGN.md
+    # section 4); the data-parallel result may sit no further from the emulation than 3x that run-to-run distance
+    grads2 = []
+    for r in range(world):
+        net2 = Network(embedding_size=128, device="cuda:0", train_dtype=torch.float16)
+        net2.load_keras_params(params)
+        tr2 = Trainer(net2, batch=6, loss="triplet", alpha=0.2, lr=0.01)
+        tr2.set_images(torch.from_numpy(structured_images(6, seed=20 + r)))
+        for ops in (tr2.pre_ops, tr2.plan.fwd, tr2.loss_ops, tr2.plan.bwd):
+            tr2.plan.run_ops(ops, net2.stream())
+        torch.cuda.synchronize()
+        grads2.append(tr2.G.clone())
+    gsum2 = (grads2[0] + grads2[1]).cpu().numpy()
+    floor = float(np.linalg.norm(gsum - gsum2) / np.linalg.norm(gsum))
+    dist_dp = float(np.linalg.norm(res[0][2] - gsum) / np.linalg.norm(gsum))
+    print(f"  relative distance DP vs emulation {dist_dp:.4f}; run-to-run noise floor {floor:.4f}")
+    assert dist_dp <= 3.0 * floor + 1e-3
+    assert cos_g > 0.97 and cos_u > 0.97
     assert abs(np.linalg.norm(upd_dp) / np.linalg.norm(upd_ref) - 1) < 0.05
+
+
+def _rank_softmax(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from facenet_amd.engine import Network
+        from facenet_amd.train import Trainer
+        from tests.util_data import structured_images
+        # every rank builds its network from a DIFFERENT seed: Trainer must broadcast rank 0's variables (MirroredStrategy)
+        net = Network(embedding_size=128, device="cuda:0", train_dtype=torch.float16, nrof_classes=19, seed=rank)
+        p_init = net.P.clone()
+        tr = Trainer(net, batch=4, loss="softmax", lr=0.01, world_size=world, process_group=dist.group.WORLD, n_buckets=4)
+        start = net.P.cpu().numpy().copy()
+        # the classifier's weight gradient is complete before backward starts: its bucket is ready at launch 0 of the backward list
+        assert tr.buckets[0][2] == net.n_kernel and len(tr.segments) == len(tr.buckets) + 1
+        tr.set_images(torch.from_numpy(structured_images(4, seed=40 + rank)), torch.tensor([(3 * rank + i) % 19 for i in range(4)]))
+        tr.capture()
+        for _ in range(2):
+            tr.step()
+        torch.cuda.synchronize()
+        mean, var = tr.averaged_moving_stats()
+        q.put((rank, start, net.P.cpu().numpy(), net.S_mean.cpu().numpy(), mean.cpu().numpy(), bool(torch.equal(p_init, net.P) or rank == 0)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_four_replicas_softmax_broadcast_buckets_and_stat_averaging():
+    """World 4 (gloo, one GPU): rank 0's variables are broadcast at construction, the classifier bucket that is ready before
+    backward is exchanged, replicas stay bit-identical through captured steps, per-replica moving statistics differ and
+    averaged_moving_stats() returns their mean on every rank."""
+    import torch.multiprocessing as mp
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_softmax, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in res[1:]:
+        assert np.array_equal(res[0][1], r[1])          # broadcast: every replica starts from rank 0's parameters
+        assert np.array_equal(res[0][2], r[2])          # and stays bit-identical after two captured steps
+        assert np.array_equal(res[0][4], r[4])          # the averaged moving statistics agree on every rank
+    assert not np.array_equal(res[0][3], res[1][3])     # per-replica BatchNorm: local moving statistics differ
+    assert np.allclose(res[0][4], sum(r[3] for r in res) / world, rtol=1e-6, atol=1e-7)
+    assert float(np.abs(res[0][2] - res[0][1]).max()) > 0

@@ -93,3 +93,41 @@ def test_bucket_construction_covers_gradients_once():
         assert b[0][2] == net.n_kernel and b[-2][1] == 0
     with pytest.raises(AssertionError):
         parallel.check_buckets([(0, 0, 10), (1, 20, 30)], 30, (30, 30))       # gap
+
+
+def test_keras_variable_names_and_order():
+    """The names and order Keras gives the reference's declaration (facenet/models/inception_resnet_v1.py:83-468): stage
+    scopes, auto-numbered blocks / tower Sequentials / BatchNormalization layers, trainable variables first."""
+    from facenet_amd import keras_names
+    from facenet_amd.engine import Network
+    net = Network(embedding_size=512, nrof_classes=10575, allocate=False)
+    table = keras_names.keras_variable_table(net.layers)
+    names = [k for k, _ in table]
+    assert len(names) == len(set(names)) == 133 + 1 + 21 + 1 + 112 * 3        # kernels (+classifier), biases (+classifier), beta/mean/var
+    assert names[0] == "inception_resnet_v1/conv2d/Conv2d_1a_3x3/kernel:0"
+    assert names[1] == "inception_resnet_v1/conv2d/batch_normalization/beta:0"
+    assert "inception_resnet_v1/block35/block35/sequential/Conv2d_1x1/kernel:0" in names          # first tower of the first Block35
+    assert "inception_resnet_v1/block35/block35_4/sequential_14/Conv2d_0c_3x3/kernel:0" in names   # 15 tower Sequentials in block35
+    assert "inception_resnet_v1/reduction_a/sequential_16/batch_normalization_39/beta:0" in names
+    assert "inception_resnet_v1/block17/block17_9/sequential_36/Conv2d_0c_7x1/kernel:0" in names
+    assert "inception_resnet_v1/reduction_b/sequential_39/batch_normalization_86/beta:0" in names
+    assert "inception_resnet_v1/block8/block8_4/Conv2d_1x1/bias:0" in names                        # `up` of the fifth repeated Block8
+    assert "inception_resnet_v1/block8_5/sequential_51/Conv2d_0c_3x1/kernel:0" in names            # the last Block8 (:453)
+    assert "inception_resnet_v1/features/logits/kernel:0" in names
+    assert "sequential_52/logits/bias:0" in names
+    # model.weights: every trainable variable, then the moving statistics
+    first_frozen = next(i for i, k in enumerate(names) if k.endswith("moving_mean:0"))
+    assert all(not k.endswith(("moving_mean:0", "moving_variance:0")) for k in names[:first_frozen])
+    assert all(k.endswith(("moving_mean:0", "moving_variance:0")) for k in names[first_frozen:])
+    assert names[first_frozen] == "inception_resnet_v1/conv2d/batch_normalization/moving_mean:0"
+    assert names[-1] == "inception_resnet_v1/features/batch_normalization_111/moving_variance:0"
+    # name mapping is a bijection onto the engine's keys, and files are matched by name in either spelling
+    params = {i: idx for idx, (_, i) in enumerate(table)}
+    keras = keras_names.to_keras(params, net.layers)
+    assert list(keras.keys()) == names
+    back = keras_names.from_keras({k[:-2]: v for k, v in keras.items()}, net.layers)     # without the ':0' suffix
+    assert back == params and keras_names.from_keras(params, net.layers) == params
+    with pytest.raises(KeyError):
+        keras_names.from_keras({k: v for k, v in keras.items() if "block17_3" not in k}, net.layers)
+    assert keras_names.optimizer_slot_names(names[0]) == ("Adam/inception_resnet_v1/conv2d/Conv2d_1a_3x3/kernel/m:0",
+                                                          "Adam/inception_resnet_v1/conv2d/Conv2d_1a_3x3/kernel/v:0")

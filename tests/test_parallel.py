@@ -1,4 +1,4 @@
-"""Data-parallel gradient exchange on CPU: 2 processes, ``gloo`` backend (the GPU path uses the same code with RCCL).
+"""Data-parallel gradient exchange on CPU: 2 and 4 processes, ``gloo`` backend (the GPU path uses the same code with RCCL).
 Checks that the bucketed SUM all-reduce + 1/world scaling reproduces the global-batch mean gradient
 (MirroredStrategy semantics, apps/train_softmax_tf2_gpus.py:49) and that replicas stay bit-identical."""
 import os
@@ -29,7 +29,9 @@ def _worker(rank, world, port, q):
         n_kernel = sum(sizes)
         tail = (n_kernel, n_kernel + 96)
         done_at = {i: 2 * (len(sizes) - i) for i in range(len(sizes))}
+        del done_at[len(sizes) - 1]     # the softmax classifier (last layer): complete inside the loss ops, before backward starts
         buckets = parallel.make_buckets(offs, sizes, done_at, n_kernel, tail, 20, n_buckets=3)
+        assert buckets[0] == (done_at[3], offs[3], n_kernel)         # first bucket: classifier + the last backbone layers, ready with the slowest
         parallel.check_buckets(buckets, n_kernel, tail)
         g = torch.Generator().manual_seed(100 + rank)
         grad = torch.randn(tail[1], generator=g)
@@ -46,8 +48,9 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_world2_gloo():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4])
+def test_bucketed_allreduce_gloo(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -57,9 +60,10 @@ def test_bucketed_allreduce_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    mean = (res[0][1] + res[1][1]) / 2
+    mean = sum(r[1] for r in res) / world
     for r in res:
         assert np.allclose(r[2], mean, atol=1e-6)             # every element reduced exactly once
         assert np.array_equal(r[3], np.zeros_like(r[3]))      # broadcast from rank 0
         assert r[4] == sorted(r[4])
-    assert np.array_equal(res[0][2], res[1][2])               # replicas hold bit-identical averaged gradients
+    for r in res[1:]:
+        assert np.array_equal(res[0][2], r[2])                # replicas hold bit-identical averaged gradients
