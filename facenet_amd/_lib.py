@@ -33,9 +33,11 @@ class ConvDesc(C.Structure):
         ("ld_bn_y", C.c_int32), ("bn_sq_off", C.c_int32), ("bn_replicas", C.c_int32), ("bn_rep_stride", C.c_int32), ("bn_relu", C.c_int32),
         ("nrm_stats", C.c_void_p), ("nrm_beta", C.c_void_p),
         ("nrm_sq_off", C.c_int32), ("nrm_replicas", C.c_int32), ("nrm_rep_stride", C.c_int32), ("nrm_count", C.c_int32),
-        ("nrm_eps", C.c_float), ("tile_fwd", C.c_int32), ("tile_dgrad", C.c_int32),
+        ("nrm_eps", C.c_float), ("nrm_z", C.c_void_p), ("tile_fwd", C.c_int32), ("tile_dgrad", C.c_int32),
         ("dy2", C.c_void_p), ("w2", C.c_void_p), ("dy3", C.c_void_p), ("w3", C.c_void_p),
         ("Cout2", C.c_int32), ("ld_y2", C.c_int32), ("Cout3", C.c_int32), ("ld_y3", C.c_int32),
+        ("rb_prev", C.c_void_p), ("rb_out", C.c_void_p), ("rb_dtrunk", C.c_void_p), ("rb_dup", C.c_void_p), ("rb_dbias", C.c_void_p),
+        ("rb_scale", C.c_float), ("rb_accumulate", C.c_int32),
     ]
 
 

@@ -135,4 +135,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Re-initialisation of small per-call state words (statistics, losses, min/max) inside launch functions that may be captured
+// into a HIP graph.  A kernel, not hipMemsetAsync: memset NODES of a replayed graph were observed (ROCm 7.2, MI355X) to be
+// skipped or reordered depending on where the caching allocator had placed the words (tools/dev_minergraph3.py: the image
+// min/max of the previous replay leaked into the next one), while kernel nodes keep stream order.
+static __global__ void fill_words_kernel(unsigned* __restrict__ p, unsigned v0, unsigned v1, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = (i & 1) ? v1 : v0;
+}
+static inline void fill_words(void* p, unsigned v0, unsigned v1, int n, hipStream_t st) {
+    hipLaunchKernelGGL(fill_words_kernel, dim3(n > 4096 ? 16 : 1), dim3(256), 0, st, (unsigned*)p, v0, v1, n);
+}
+
 }  // namespace fn

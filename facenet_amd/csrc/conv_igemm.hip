@@ -71,6 +71,12 @@ struct ConvArgs {
     const float* nrm_beta;
     int nrm_sq_off, nrm_replicas, nrm_rep_stride, nrm_count;
     float nrm_eps;
+    unsigned short* nrm_z;    // optional: the normalised operand is also written here (geometry of src), see fn_conv_desc.nrm_z
+    // dgrad epilogue: fused residual backward (fn_conv_desc.rb_*).  `resid` (scale 1) carries rb_prev, `out` is rb_dtrunk.
+    const unsigned short* mask;   // rows of the block's forward output: values <= 0 zero the gradient
+    unsigned short* out2;         // scale2 * (masked gradient), geometry of out
+    float* colsum;                // += column sums of what goes to out2
+    float scale2;
 };
 
 // q = m / d, r = m % d through the hardware reciprocal (0 <= m < 2^24, d > 0): integer division is a ~40-instruction
@@ -154,15 +160,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     int* sRow = reinterpret_cast<int*>(sT + (PLAIN ? 0 : ((a.KTOT + BK - 1) / BK) * 8));   // [BM] output pixel of every tile row (class mode)
     float* sNs = reinterpret_cast<float*>(sRow + BM);   // NORM: [CS] scale, [CS] shift of the source channels
     float* sNh = sNs + a.CS;
-    if constexpr (NORM) {
-        for (int c = tid; c < a.CS; c += NT) {
-            float sc, sh, mean, var;
-            bn_batch_affine(a.nrm_stats, c, a.nrm_sq_off, a.nrm_replicas, a.nrm_rep_stride, a.nrm_count, a.nrm_eps, a.nrm_beta[c], sc, sh,
-                            mean, var);
-            sNs[c] = sc;
-            sNh[c] = sh;
-        }
-    }
 
     // Operand addressing.  Both operands are read with BUFFER loads (32-bit byte offsets against a resource descriptor):
     // an offset at or beyond num_records returns zeros without touching memory, so padding, ragged rows / columns and the
@@ -175,6 +172,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     constexpr unsigned OOB = 0x60000000u;
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.src), 0, a.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, a.w_bytes, 0x00020000);
+    // NORM with nrm_z: the workgroups of the first column tile also write the normalised operand (the activated tensor)
+    const bool side_write = NORM && a.nrm_z != nullptr && tn == 0;
     if constexpr (!PLAIN) {
         for (int i = tid; i < ntiles_k * 8; i += NT) {
             const int e = a.s2 ? ktab_entry_s2(i, a.CS, a.KH, a.KW, qy, qx) : ktab_entry(i, a.KTOT, a.CS, a.KW);
@@ -185,6 +184,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
                 t.x = (int)(((unsigned)(dy & 0xff) << 24) | ((unsigned)(dx & 0xff) << 16) | (unsigned)c);
                 t.y = ((dy * a.SW + dx) * a.ld_src + c) * 2;
                 t.z = ((ky * a.KW + kx) * a.CS + c) * 2;
+                t.w = (!a.s2 && ky + a.offy == 0 && kx + a.offx == 0) ? 1 : 0;   // centre tap: source pixel == output pixel
             }
             sT[i] = t;
         }
@@ -303,9 +303,19 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     };
     auto store_tile = [&](int buf, const u32x4 (&ra)[AP], const u32x4 (&rb)[BP], const unsigned msk, const int kt) {
         float nsc[8], nsh[8];
+        unsigned zoff = 0u;       // NORM side write: byte offset of this thread's chunk relative to its row's pixel
+        bool zw = false;
         if constexpr (NORM) {   // the 8 source channels of this thread's chunk of tile kt
             int c = kt * BK + kg * 8;
-            if constexpr (!PLAIN) c = sT[kt * 8 + kg].x & 0xffff;
+            if constexpr (!PLAIN) {
+                const int4 te = sT[kt * 8 + kg];
+                c = te.x & 0xffff;
+                zoff = (unsigned)te.y;
+                zw = side_write && te.w != 0;
+            } else {
+                zoff = (unsigned)c * 2u;
+                zw = side_write;
+            }
             if (msk) {
                 const f32x4 s0 = *reinterpret_cast<const f32x4*>(sNs + c), s1 = *reinterpret_cast<const f32x4*>(sNs + c + 4);
                 const f32x4 h0 = *reinterpret_cast<const f32x4*>(sNh + c), h1 = *reinterpret_cast<const f32x4*>(sNh + c + 4);
@@ -324,6 +334,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = fmaxf(fmaf(f[e], nsc[e], nsh[e]), 0.f);
                     v = pack8<T>(f);
+                    // a real (in-range) chunk of the centre tap is element (output pixel, channel) of the source itself.
+                    // The clamped tail iterations restage the last tile: they store the same bytes again.
+                    if (zw) *(FN_GLOBAL u32x4*)((FN_GLOBAL unsigned char*)a.nrm_z + (size_t)(rbyte[i] + zoff)) = v;
                 }
             }
             *reinterpret_cast<u32x4*>(sA + buf * A_BYTES + r * 128 + ((kg ^ (r & 7)) << 4)) = v;
@@ -373,6 +386,34 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         auto tile_of = [&](int it) { return grp + KS * it; };   // it-th k tile of this group
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) load_tile(min(tile_of(d), last), ra[d], rb[d], rmask[d]);
+        if constexpr (NORM) {
+            // scale / shift of the source channels from the producer's statistic replicas -- AFTER the first operand loads have
+            // been issued, so the two memory round trips overlap; (channel, replica quarter) pairs spread over all threads
+            float* sPart = reinterpret_cast<float*>(smem + grp * STAGE_BYTES);     // staging LDS is still free: [8][CS]
+            const int CS = a.CS;
+            for (int i = tid; i < 4 * CS; i += NT) {
+                const int c = i % CS, q = i / CS;
+                float s1 = 0.f, s2 = 0.f;
+                for (int rp = q; rp < a.nrm_replicas; rp += 4) {
+                    s1 += a.nrm_stats[(long)rp * a.nrm_rep_stride + c];
+                    s2 += a.nrm_stats[(long)rp * a.nrm_rep_stride + a.nrm_sq_off + c];
+                }
+                sPart[q * CS + c] = s1;
+                sPart[(4 + q) * CS + c] = s2;
+            }
+            __syncthreads();
+            for (int c = tid; c < CS; c += NT) {      // same combination order as bn_batch_affine / bn_relu_fwd_kernel: same bits
+                const float s1 = sPart[c] + sPart[CS + c] + sPart[2 * CS + c] + sPart[3 * CS + c];
+                const float s2 = sPart[4 * CS + c] + sPart[5 * CS + c] + sPart[6 * CS + c] + sPart[7 * CS + c];
+                const float inv = 1.f / (float)a.nrm_count;
+                const float mean = s1 * inv;
+                const float var = fmaxf(s2 * inv - mean * mean, 0.f);
+                const float sc = rsqrtf(var + a.nrm_eps);
+                sNs[c] = sc;
+                sNh[c] = a.nrm_beta[c] - mean * sc;
+            }
+            __syncthreads();
+        }
         store_tile(0, ra[0], rb[0], rmask[0], min(tile_of(0), last));
         __syncthreads();
         for (int it0 = 0; it0 < n_iter; it0 += DEPTH) {
@@ -484,6 +525,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
                 for (int e = 0; e < 8; ++e) v[e] = rv[e] + a.scale * v[e];
             }
             const long o = (long)m * a.ld_out + col;
+            if (a.mask) {   // fused residual backward: ReLU mask of the block output, then the scaled copy for the `up` branch
+                float mk[8];
+                unpack8<T>(*reinterpret_cast<const u32x4*>(a.mask + o), mk);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+            }
+            if (a.out2) {
+                float u[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { u[e] = a.scale2 * v[e]; bq1[e] += u[e]; }
+                *reinterpret_cast<u32x4*>(a.out2 + o) = pack8<T>(u);
+            }
             if (a.bn_y) {   // dgrad only (no resid/relu/f32 here): v is the complete gradient unless accumulating
                 float yy[8], tot[8];
                 unpack8<T>(*reinterpret_cast<const u32x4*>(a.bn_y + (long)m * a.ld_bn_y + col), yy);
@@ -534,7 +587,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             }
         }
     }
-    if (a.bn_y) {   // fold the RP row lanes through LDS (the C tile is no longer needed), one atomic per column per block
+    if (a.bn_y || a.out2) {   // fold the RP row lanes through LDS (the C tile is no longer needed), one atomic per column per block
         __syncthreads();
         float* sP = reinterpret_cast<float*>(smem);   // [RP][2*BN]
         if (active) {
@@ -551,8 +604,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
                 float sum = 0.f;
 #pragma unroll 8
                 for (int t = 0; t < RP; ++t) sum += sP[t * 2 * BN + tid];
-                float* ap = a.bn_acc + (long)(tm % a.bn_replicas) * a.bn_rep_stride + (tid < BN ? 0 : a.bn_sq_off);
-                atomicAdd(&ap[n0 + c], sum);
+                if (a.out2) {
+                    if (tid < BN) atomicAdd(&a.colsum[n0 + c], sum);
+                } else {
+                    float* ap = a.bn_acc + (long)(tm % a.bn_replicas) * a.bn_rep_stride + (tid < BN ? 0 : a.bn_sq_off);
+                    atomicAdd(&ap[n0 + c], sum);
+                }
             }
         }
     }
@@ -1119,6 +1176,12 @@ static int make_fwd_args(const fn_conv_desc* d, ConvArgs& a) {
         a.nrm_stats = d->nrm_stats; a.nrm_beta = d->nrm_beta; a.nrm_sq_off = d->nrm_sq_off;
         a.nrm_replicas = d->nrm_replicas > 0 ? d->nrm_replicas : 1; a.nrm_rep_stride = d->nrm_rep_stride;
         a.nrm_count = d->nrm_count; a.nrm_eps = d->nrm_eps;
+        if (d->nrm_z) {
+            FN_REQUIRE(d->stride == 1 && d->OH == d->H && d->OW == d->W, "conv_fwd: nrm_z needs stride 1 and an output map of the input's size");
+            a.nrm_z = (unsigned short*)d->nrm_z;
+        }
+    } else {
+        FN_REQUIRE(!d->nrm_z, "conv_fwd: nrm_z without nrm_stats");
     }
     return FN_OK;
 }
@@ -1126,7 +1189,7 @@ static int make_fwd_args(const fn_conv_desc* d, ConvArgs& a) {
 // dX[n,iy,ix,ci] = sum_{ky,kx,co} dY[n,(iy+pad-ky)/s,(ix+pad-kx)/s,co] * Wt[ci][ky,kx][co]
 static int make_dgrad_args(const fn_conv_desc* d, ConvArgs& a) {
     if (int rc = check_desc(d)) return rc;
-    FN_REQUIRE(d->y && d->w && d->dx, "conv_dgrad: null dy/wt/dx");
+    FN_REQUIRE(d->y && d->w && (d->dx || d->rb_dup), "conv_dgrad: null dy/wt/dx");
     FN_REQUIRE(d->Cout % 8 == 0 && d->ld_y % 8 == 0 && d->ld_y >= d->Cout, "conv_dgrad: Cout=%d ld_y=%d must be multiples of 8", d->Cout,
                d->ld_y);
     a = ConvArgs{};
@@ -1162,6 +1225,13 @@ static int make_dgrad_args(const fn_conv_desc* d, ConvArgs& a) {
             a.src3_bytes = (int)(pix * d->ld_y3 * 2); a.w3_bytes = d->Cin * d->Cout3 * 2;
             a.nt_total = a.t2 + cdiv(a.K3, 64);
         }
+    }
+    if (d->rb_dup) {
+        FN_REQUIRE(d->rb_dtrunk && d->rb_dbias && !d->bn_y && !d->out_f32 && d->Cin % 8 == 0 && d->ld_x % 8 == 0,
+                   "conv_dgrad: fused residual backward needs rb_dtrunk, rb_dbias, a low-precision dx geometry and no fused BN reduction");
+        a.out = d->rb_dtrunk; a.accumulate = d->rb_accumulate;
+        a.resid = (const unsigned short*)d->rb_prev; a.ld_res = d->ld_x; a.scale = 1.f;
+        a.mask = (const unsigned short*)d->rb_out; a.out2 = (unsigned short*)d->rb_dup; a.colsum = d->rb_dbias; a.scale2 = d->rb_scale;
     }
     if (d->bn_y) {
         FN_REQUIRE(!d->accumulate && !d->out_f32 && d->bn_scale && d->bn_shift && d->bn_beta && d->bn_acc && d->ld_bn_y % 8 == 0,

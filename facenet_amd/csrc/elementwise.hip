@@ -687,7 +687,7 @@ static int image_normalize_impl(const SRC* img, void* out, float* work, int N, i
     FN_REQUIRE(mode == 0 || mode == 1, "Invalid image normalization algorithm");  // facenet.py:82
     FN_REQUIRE(((uintptr_t)img & 15) == 0 && ((long)HW * 3 * sizeof(SRC)) % 16 == 0, "image_normalize: images must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(work, 0, sizeof(float) * 4 * N, st) != hipSuccess) { set_error("image_normalize: memset failed"); return FN_ELAUNCH; }
+    fill_words(work, 0u, 0u, 4 * N, st);
     hipLaunchKernelGGL(img_stats_kernel<SRC>, dim3(8, N), dim3(256), 0, st, img, (unsigned*)work, HW * 3);
     const int gx = grid_for(HW, 256, 32);
     if (dtype == FN_BF16) hipLaunchKernelGGL((img_apply_kernel<__bf16, SRC>), dim3(gx, N), dim3(256), 0, st, img, (unsigned short*)out, (const unsigned*)work, HW, mode);

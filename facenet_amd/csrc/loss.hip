@@ -22,29 +22,31 @@ __global__ __launch_bounds__(256) void pairwise_kernel(const float* __restrict__
     const int i = blockIdx.y;
     const int jb = (blockIdx.x * 4 + wave) * 16;
     if (jb >= m) return;
-    // this lane's slice of row i stays in registers (E <= 64*8)
+    // this lane's slice of row i stays in registers (E <= 64*8).  Every sum below is an explicit fma chain in ONE fixed order,
+    // and a row's squared norm is computed by the same code whether the row is an `a` or a `b`: out[i][j] and out[j][i] are
+    // then the same bits (|a|^2 + |b|^2 commutes, the dot product's terms commute), which the triplet selection relies on
+    // when it reads columns instead of rows.  Left to the compiler's contraction choices the two norms differed in the last bit.
     float a[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) a[t] = (lane + 64 * t < E) ? xa[(long)i * E + lane + 64 * t] : 0.f;
     float asq = 0.f;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) asq += a[t] * a[t];
+    for (int t = 0; t < 8; ++t) asq = __fmaf_rn(a[t], a[t], asq);
     asq = wave_sum(asq);
     float lo = 3e38f, hi = -3e38f;
     for (int j = jb; j < min(m, jb + 16); ++j) {
         float d = 0.f, bsq = 0.f;
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-            if (lane + 64 * t < E) {
-                const float b = xb[(long)j * E + lane + 64 * t];
-                d += a[t] * b;
-                bsq += b * b;
-            }
+        for (int t = 0; t < 8; ++t) {
+            const float b = (lane + 64 * t < E) ? xb[(long)j * E + lane + 64 * t] : 0.f;
+            d = __fmaf_rn(a[t], b, d);
+            bsq = __fmaf_rn(b, b, bsq);
+        }
         d = wave_sum(d);
         float r;
         if (metric == 2) {
             bsq = wave_sum(bsq);
-            r = fmaxf(asq + bsq - 2.f * d, 0.f);
+            r = fmaxf(__fmaf_rn(-2.f, d, asq + bsq), 0.f);
         } else {
             lo = fminf(lo, d);
             hi = fmaxf(hi, d);
@@ -261,13 +263,7 @@ extern "C" int fn_pairwise_sqdist(const float* xa, const float* xb, float* out, 
     FN_REQUIRE(metric >= 0 && metric <= 2, "Undefined similarity metric %d", metric);  // statistics.py:55
     hipStream_t st = (hipStream_t)stream;
     if (range) {
-        const int init[2] = {0x7f7fffff, (int)0x80800000};  // ord(+FLT_MAX), ord(-FLT_MAX)
-        // two 4-byte memsets keep the call capturable (no host staging buffer)
-        if (hipMemsetD32Async((hipDeviceptr_t)range, init[0], 1, st) != hipSuccess ||
-            hipMemsetD32Async((hipDeviceptr_t)((int*)range + 1), init[1], 1, st) != hipSuccess) {
-            set_error("pairwise_sqdist: memset failed");
-            return FN_ELAUNCH;
-        }
+        fill_words(range, 0x7f7fffffu, 0x80800000u, 2, st);   // ord(+FLT_MAX), ord(-FLT_MAX); a kernel node, see fill_words
     }
     hipLaunchKernelGGL(pairwise_kernel, dim3(cdiv(m, 64), n), dim3(256), 0, st, xa, xb, out, (int*)range, n, m, E, metric);
     return check_launch("pairwise_sqdist");
@@ -287,7 +283,7 @@ extern "C" int fn_select_triplets(const float* dist, const int32_t* labels, int 
 extern "C" int fn_triplet_loss_fwd_bwd(const float* emb, float* demb, float* loss, int T, int E, float alpha, void* stream) {
     FN_REQUIRE(emb && loss && T > 0 && E > 0, "triplet_loss: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) { set_error("triplet_loss: memset failed"); return FN_ELAUNCH; }
+    fill_words(loss, 0u, 0u, 1, st);
     hipLaunchKernelGGL(triplet_loss_kernel, dim3(cdiv(T, 4)), dim3(256), 0, st, emb, demb, loss, T, E, alpha);
     return check_launch("triplet_loss");
 }
@@ -297,7 +293,7 @@ extern "C" int fn_softmax_xent_fwd_bwd(const float* logits, int ld, const int32_
     FN_REQUIRE(dtype == FN_BF16 || dtype == FN_F16, "dtype %d unsupported", dtype);
     FN_REQUIRE(logits && labels && loss && N > 0 && C > 0 && ld >= C && (!dlogits_lp || ld_d >= C), "softmax_xent: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) { set_error("softmax_xent: memset failed"); return FN_ELAUNCH; }
+    fill_words(loss, 0u, 0u, 1, st);
     if (dtype == FN_BF16)
         hipLaunchKernelGGL(softmax_xent_kernel<__bf16>, dim3(N), dim3(256), 0, st, logits, ld, labels, loss, (unsigned short*)dlogits_lp, ld_d, dbias, N, C, grad_scale);
     else

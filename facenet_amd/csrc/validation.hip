@@ -113,14 +113,8 @@ extern "C" int fn_confidence_counts(const float* emb, const int32_t* cls_start, 
     FN_REQUIRE(emb && cls_start && thresholds && out && C > 0 && E > 0 && T > 0 && T <= VMAXT, "confidence_counts: bad arguments (T <= 256)");
     FN_REQUIRE(metric == 0 || metric == 1, "Undefined similarity metric %d", metric);   // statistics.py:258-260
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(out, 0, sizeof(double) * 4 * T, st) != hipSuccess) { set_error("confidence_counts: memset failed"); return FN_ELAUNCH; }
-    if (range) {
-        if (hipMemsetD32Async((hipDeviceptr_t)range, 0x7f7fffff, 1, st) != hipSuccess ||
-            hipMemsetD32Async((hipDeviceptr_t)(range + 1), (int)0x80800000, 1, st) != hipSuccess) {
-            set_error("confidence_counts: memset failed");
-            return FN_ELAUNCH;
-        }
-    }
+    fill_words(out, 0u, 0u, 2 * 4 * T, st);                              // 4*T doubles; kernel nodes, see fill_words
+    if (range) fill_words(range, 0x7f7fffffu, 0x80800000u, 2, st);
     const long pairs = (long)C * (C + 1) / 2;
     FN_REQUIRE(pairs < (1L << 31), "confidence_counts: too many classes");
     hipLaunchKernelGGL(confidence_kernel, dim3((unsigned)pairs), dim3(256), 0, st, emb, cls_start, C, E, thresholds, T, metric, out, (int*)range);

@@ -324,14 +324,16 @@ class Network:
     def load_keras_params(self, params: Dict[str, torch.Tensor]):
         """``params``: Keras-layout tensors keyed by Keras variable names (keras_names.py: the names and order the reference's
         declaration produces) or by the engine's ``<layer>/kernel`` keys; matched by name."""
-        from . import keras_names
-        params = keras_names.from_keras(params, self.layers, int(self.cfg["block8_1"]["repeat"]))
-        P, mean, var = self._flat(params, with_stats=True)
+        P, mean, var = self._flat(self._engine_keys(params), with_stats=True)
         self.P.copy_(P)
         self.S_mean.copy_(mean)
         self.S_var.copy_(var)
         self.folded_valid = False
         self.refresh_packs()
+
+    def _engine_keys(self, params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        from . import keras_names
+        return keras_names.from_keras(params, self.layers, int(self.cfg["block8_1"]["repeat"]))
 
     def keras_variables(self, moving_stats: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> "OrderedDict[str, torch.Tensor]":
         """``model.weights`` of the reference model: Keras variable names, Keras layouts, Keras order (keras_names.py)."""
@@ -435,24 +437,29 @@ class BlockNetwork(Network):
     forward + backward parity tests ("block" level): ``plan.bufs['trunk']`` is the input (``.act`` in,
     ``.grad`` out), ``plan.embedding`` the block output (``.act`` out, ``.grad`` in)."""
 
-    def __init__(self, kind: str, H: int, W: int, C: int, scale: float = 0.17, relu: bool = True, filters=None, **kw):
+    def __init__(self, kind: str, H: int, W: int, C: int, scale: float = 0.17, relu: bool = True, filters=None, repeat: int = 1, **kw):
         if kind not in BLOCK_TOWERS and kind not in ("reduction_a", "reduction_b"):
             raise ValueError(f"unknown block kind {kind!r}")
-        self._blk = (kind, H, W, C, float(scale), bool(relu), filters)
+        self._blk = (kind, H, W, C, float(scale), bool(relu), filters, int(repeat))
         super().__init__(embedding_size=8, **kw)
 
     def _topology(self, g: "Lowering"):
-        kind, H, W, C, scale, relu, filters = self._blk
+        kind, H, W, C, scale, relu, filters, repeat = self._blk
         x = g.feature_input(H, W, C)
-        if kind in BLOCK_TOWERS:
+        if kind in BLOCK_TOWERS:                 # `repeat` chained blocks "<kind>/<i>", like the repeated stages of the model
             towers, up = BLOCK_TOWERS[kind]
             if up != C:
                 raise ValueError(f"{kind} expects {up} input channels, got {C}")
-            return g.block(kind, x, towers, up, scale, relu)
+            for i in range(repeat):
+                x = g.block(f"{kind}/{i}", x, towers, up, scale, relu)
+            return x
         return g.reduction(kind, x, reduction_towers(kind, filters or DEFAULT_CONFIG[kind]["filters"]))
 
     def _bn_prefix(self, L: Layer) -> str:
         return L.name + "/bn"
+
+    def _engine_keys(self, params):
+        return params          # a lone block has no place in the reference model's variable naming: engine keys only
 
 
 # ------------------------------------------------------------------------------------------------
@@ -468,7 +475,23 @@ class Lowering:
         # launches and the activated copies, but every tap and every N tile repeats the per-element affine+ReLU, which makes
         # the staging VALU-bound: measured 9.52 ms vs 9.11 ms per step on MI355X -> off by default.
         self.norm_on_load = bool(int(os.environ.get("FACENET_NORM_ON_LOAD", "0")))
+        # Optional (FACENET_LAZY_BN_MAXHW=17; default 0 = off): on maps up to that size a BN+ReLU output with exactly ONE reader, a
+        # stride-1 convolution whose output map has the input's size, is materialised BY that reader -- it normalises the raw
+        # tensor while staging its operand and the workgroups of its first column tile write the activated tensor once, at the
+        # centre tap (fn_conv_desc.nrm_z); the weight gradient and the backward pass read the same buffers as before.  70 of the
+        # 82 fn_bn_relu_train_fwd launches disappear, but the step does not get faster (MI355X, batch 90: 7.58-7.60 ms with,
+        # 7.54 ms without): normalise-on-load costs each reader 2.5-4.5 us (tools/dev_normcost.py: a dependent statistics round
+        # trip in the prologue plus ~40 VALU instructions per 16-byte chunk on the load -> LDS path of a latency-bound k loop,
+        # repeated per tap and per column tile), which is what the removed launch and its boundary cost.  Kept as an option.
+        self.lazy_bn_maxhw = int(os.environ.get("FACENET_LAZY_BN_MAXHW", "0"))
+        self.lazy_bn_kmax = int(os.environ.get("FACENET_LAZY_BN_KMAX", "1024"))      # k x k readers only up to this many K columns
+        self.lazy: Dict[str, List[Tuple[int, int]]] = {}        # buffer -> [(c0, C)] BN ranges materialised by their reader
         self.merge_sibling_dgrads = bool(int(os.environ.get("FACENET_MERGE_SIBLINGS", "1")))
+        # The residual backward of block i (ReLU mask, scaled copy for its `up` branch, bias gradient, pass-through to its
+        # trunk) runs in the epilogue of the launch that completes the gradient of block i's output: the merged sibling data
+        # gradient of block i+1 (fn_conv_desc.rb_*).  18 of the 21 fn_residual_bwd launches and one read-modify-write pass over
+        # every block output's gradient disappear.
+        self.fuse_residual_bwd = bool(int(os.environ.get("FACENET_FUSE_RESIDUAL_BWD", "1")))
         self.virtual: Dict[str, List[Tuple[int, int]]] = {}     # buffer -> [(c0, C)] BN ranges that are not materialised
         self.dtype = net.train_dtype if training else net.infer_dtype
         self.dt = None if declare else _lib.dtype_code(self.dtype)
@@ -680,6 +703,7 @@ class Lowering:
             self.head_mean = torch.zeros(net.E, dtype=torch.float32, device=dev)
             self.head_rstd = torch.zeros(net.E, dtype=torch.float32, device=dev)
             self._find_virtual()
+            self._find_lazy()
             self.fin_reps = torch.zeros(CB, dtype=torch.int32)
             self.fin_count = torch.ones(CB, dtype=torch.int32)
         inp = self.bufs.get("input")
@@ -689,7 +713,7 @@ class Lowering:
                        r=[region(self.images)], w=[self._ra(inp.full()), region(self.norm_work)])
         for r in self.recs:
             getattr(self, "_fwd_" + r.kind)(r)
-        if self.training and self.virtual:
+        if self.training and (self.virtual or self.lazy):
             self.fin_reps, self.fin_count = self.fin_reps.to(dev), self.fin_count.to(dev)
             self._emit(self.fwd, "bn_finalize", lib.fn_bn_finalize, _ptr(self.ws), CB, 2 * CB, _ptr(self.fin_reps), _ptr(self.fin_count),
                        _ptr(net.P, net.beta_base), _ptr(self.save_scale), _ptr(self.save_shift), _ptr(net.S_mean), _ptr(net.S_var),
@@ -719,6 +743,36 @@ class Lowering:
             if ok:
                 self.virtual.setdefault(b.name, []).append((c0, Cc))
 
+    def _find_lazy(self):
+        """BN(+ReLU) ranges that their single reader materialises (see __init__)."""
+        if self.lazy_bn_maxhw <= 0:
+            return
+        for rec in self.recs:
+            if rec.kind != "bn" or not rec.extra["relu"]:
+                continue
+            b, c0, Cc = rec.y.buf, rec.y.c0, rec.y.C
+            if b.raw is None or max(b.H, b.W) > self.lazy_bn_maxhw or self._is_virtual(rec.y):
+                continue
+            readers = []
+            for r2 in self.recs:
+                if r2.kind == "bn":
+                    continue
+                t = r2.extra.get("trunk") if r2.kind == "conv" else None
+                touches = (r2.x is not None and r2.x.buf is b and r2.x.c0 < c0 + Cc and c0 < r2.x.c0 + r2.x.C) or \
+                          (t is not None and t.buf is b and t.c0 < c0 + Cc and c0 < t.c0 + t.C)
+                if touches:
+                    readers.append(r2)
+            if len(readers) != 1:
+                continue
+            r2 = readers[0]
+            L = r2.layer
+            if (r2.kind == "conv" and r2.x.buf is b and r2.x.c0 == c0 and r2.x.C == Cc and L.stride == 1 and L.cin <= 512
+                    and r2.y.buf.H == b.H and r2.y.buf.W == b.W and (L.kh * L.kw == 1 or L.ktot <= self.lazy_bn_kmax)):
+                self.lazy.setdefault(b.name, []).append((c0, Cc))
+
+    def _is_lazy(self, s: Slice) -> bool:
+        return any(c0 == s.c0 and Cc == s.C for (c0, Cc) in self.lazy.get(s.buf.name, []))
+
     def _is_virtual(self, s: Slice) -> bool:
         return any(c0 <= s.c0 and s.c0 + s.C <= c0 + Cc for (c0, Cc) in self.virtual.get(s.buf.name, []))
 
@@ -741,6 +795,10 @@ class Lowering:
         if self.training and self._is_virtual(r.x):
             reads, writes = [], []
             self._norm_operand(d, r.x, reads)
+        elif self.training and self._is_lazy(r.x):
+            reads, writes = [], [self._ra(r.x)]
+            self._norm_operand(d, r.x, reads)
+            d.nrm_z = _ptr(r.x.buf.act, r.x.c0)        # this launch writes the activated tensor it normalises
         else:
             d.x = _ptr(r.x.buf.act, r.x.c0)
             reads, writes = [self._ra(r.x)], []
@@ -792,7 +850,7 @@ class Lowering:
         net, lib = self.net, self.net.lib
         b, c0, Cc = r.y.buf, r.y.c0, r.y.C
         o = b.bn_off + c0
-        if self._is_virtual(r.y):
+        if self._is_virtual(r.y) or self._is_lazy(r.y):
             self.fin_reps[o:o + Cc] = self._replicas(b.M)
             self.fin_count[o:o + Cc] = b.M
             return
@@ -848,6 +906,9 @@ class Lowering:
                         and L.pad_w == 0 and r.x.buf.name != "input"):
                     self._siblings.setdefault((r.x.buf.name, r.x.c0, r.x.C), []).append(r)
             self._siblings = {k: v for k, v in self._siblings.items() if 2 <= len(v) <= 3}
+        self._resid_of: Dict[str, Rec] = {r.y.buf.name: r for r in self.recs if r.kind == "conv" and r.extra.get("kind") == "resid"}
+        for r in self.recs:
+            r.extra.pop("rb_fused", None)
         for r in reversed(self.recs):
             getattr(self, "_bwd_" + r.kind)(r)
 
@@ -871,12 +932,15 @@ class Lowering:
             t: Slice = r.extra["trunk"]
             # one scratch per block: the weight gradient of this block may still be reading it while the next block's
             # residual backward runs on another stream
-            dup = torch.zeros(y.buf.M, y.buf.C, dtype=self.dtype, device=net.device)
-            self._dup[L.name] = dup
-            acc = self._grad_mode(t)
-            self._emit(self.bwd, "residual_bwd:" + L.name, lib.fn_residual_bwd, _ptr(y.buf.grad), _ptr(y.buf.act), _ptr(t.buf.grad),
-                       _ptr(dup), _ptr(net.G, L.bias_off), y.buf.M, y.buf.C, r.extra["scale"], 1 if r.extra["relu"] else 0, acc, self.dt,
-                       r=[self._rg(y), self._ra(y)], w=[self._rg(t), region(dup), region(net.G, L.bias_off, L.bias_off + L.cout)])
+            if r.extra.get("rb_fused"):      # done by the epilogue of the launch that completed y's gradient (see _fuse_residual)
+                dup = self._dup[L.name]
+            else:
+                dup = torch.zeros(y.buf.M, y.buf.C, dtype=self.dtype, device=net.device)
+                self._dup[L.name] = dup
+                acc = self._grad_mode(t)
+                self._emit(self.bwd, "residual_bwd:" + L.name, lib.fn_residual_bwd, _ptr(y.buf.grad), _ptr(y.buf.act), _ptr(t.buf.grad),
+                           _ptr(dup), _ptr(net.G, L.bias_off), y.buf.M, y.buf.C, r.extra["scale"], 1 if r.extra["relu"] else 0, acc, self.dt,
+                           r=[self._rg(y), self._ra(y)], w=[self._rg(t), region(dup), region(net.G, L.bias_off, L.bias_off + L.cout)])
             dy_ptr, ld_dy, dy_reg = _ptr(dup), y.buf.C, region(dup)
         elif kind == "f32":
             dy_ptr, ld_dy, dy_reg = _ptr(self.head_dy), net.E, region(self.head_dy)
@@ -906,6 +970,8 @@ class Lowering:
                 g.dx = _ptr(x.buf.grad, x.c0)
                 g.accumulate = self._grad_mode(x)
                 rd = [reg0, region(net.Wt_train, L0.w_off, L0.w_off + L0.numel)]
+                wr = [self._rg(x)]
+                self._fuse_residual(g, x, rd, wr)
                 for i, (Li, pi, ldi, regi) in enumerate(rest):
                     setattr(g, ("dy2", "dy3")[i], pi)
                     setattr(g, ("w2", "w3")[i], _ptr(net.Wt_train, Li.w_off))
@@ -913,7 +979,7 @@ class Lowering:
                     setattr(g, ("ld_y2", "ld_y3")[i], ldi)
                     rd += [regi, region(net.Wt_train, Li.w_off, Li.w_off + Li.numel)]
                 self._emit(self.bwd, "conv_dgrad:" + "+".join(p[0].name for p in pend), lib.fn_conv2d_dgrad, C.byref(g), keep=(g,),
-                           r=rd, w=[self._rg(x)])
+                           r=rd, w=wr)
         elif x.buf.name != "input":
             g = self._desc(L, x, y)
             g.ld_y = ld_dy
@@ -938,6 +1004,31 @@ class Lowering:
                 wr.append((self.ws_b.data_ptr() + 1, o, o + x.C))
             self._emit(self.bwd, "conv_dgrad:" + L.name, lib.fn_conv2d_dgrad, C.byref(g), keep=(g,), r=rd, w=wr)
         self._mark(L)
+
+    def _fuse_residual(self, g: ConvDesc, x: Slice, rd: list, wr: list):
+        """`g` is the launch that completes the gradient of x.  When x is the whole output of a residual block and `g` only adds
+        to what the next block's residual backward already left there, the block's own residual backward moves into g's epilogue
+        (fn_conv_desc.rb_*): nothing else ever reads the completed gradient of x, so it is not even written."""
+        net = self.net
+        prev = self._resid_of.get(x.buf.name)
+        if not (self.fuse_residual_bwd and prev is not None and g.accumulate == 1 and x.c0 == 0 and x.C == x.buf.C):
+            return
+        Lp, t = prev.layer, prev.extra["trunk"]
+        if not (t.c0 == 0 and t.C == t.buf.C == x.buf.C):
+            return
+        dup = torch.zeros(x.buf.M, x.buf.C, dtype=self.dtype, device=net.device)
+        self._dup[Lp.name] = dup
+        prev.extra["rb_fused"] = True
+        g.accumulate = 0
+        g.rb_prev = _ptr(x.buf.grad)
+        g.rb_out = _ptr(x.buf.act) if prev.extra["relu"] else None
+        g.rb_dtrunk = _ptr(t.buf.grad)
+        g.rb_accumulate = self._grad_mode(t)
+        g.rb_dup = _ptr(dup)
+        g.rb_dbias = _ptr(net.G, Lp.bias_off)
+        g.rb_scale = float(prev.extra["scale"])
+        rd += [self._rg(x), self._ra(x)]
+        wr[:] = [self._rg(t), region(dup), region(net.G, Lp.bias_off, Lp.bias_off + Lp.cout)]
 
     def _bwd_bn(self, r: Rec):
         net = self.net

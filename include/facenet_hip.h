@@ -74,6 +74,11 @@ typedef struct fn_conv_desc {
     const float* nrm_beta;
     int32_t nrm_sq_off, nrm_replicas, nrm_rep_stride, nrm_count;
     float nrm_eps;
+    /* fwd, optional with nrm_stats: the convolution also MATERIALISES the activated tensor it normalises -- nrm_z has the
+     * geometry of x (same ld_x); every element is written exactly once, by the workgroups of the first Cout tile while they
+     * stage the centre tap.  Needs stride 1 and OH x OW == H x W (1x1, or 'same' padding).  This replaces the
+     * fn_bn_relu_train_fwd launch of the producing layer; the weight gradient then reads nrm_z like any activation. */
+    void* nrm_z;
     /* fwd / dgrad tile variant: 0 = library heuristic, BM*1000+BN with BM, BN in {128, 64, 32} = caller's choice (the host side
      * times the candidates once per plan: facenet_amd/engine.py autotune).  Results do not depend on the tile beyond the
      * summation order. */
@@ -87,6 +92,21 @@ typedef struct fn_conv_desc {
     const void* dy3;
     const void* w3;
     int32_t Cout2, ld_y2, Cout3, ld_y3;
+    /* dgrad, optional: the RESIDUAL BACKWARD of the block whose output is x, fused into this launch's epilogue (it is the last
+     * producer of that output's gradient; inception_resnet_v1.py:145-148,199-202,254-257: out = act(trunk + scale*(up + bias))).
+     *   total = this data gradient + rb_prev        rb_prev : gradient x has received so far (geometry of dx), or NULL
+     *   g     = rb_out ? total * (rb_out > 0) : total rb_out  : the block's forward output (ReLU mask), NULL = no activation
+     *   rb_dtrunk (+)= g                             gradient of the block's trunk input; rb_accumulate: add to what it holds
+     *   rb_dup = rb_scale * g                        gradient of the block's `up` convolution output
+     *   rb_dbias[c] += sum over pixels of rb_dup     (fp32, the `up` bias gradient)
+     * All four tensors have dx's geometry (ld_x).  dx itself is not written.  rb_dup == NULL: ordinary data gradient. */
+    const void* rb_prev;
+    const void* rb_out;
+    void* rb_dtrunk;
+    void* rb_dup;
+    float* rb_dbias;
+    float rb_scale;
+    int32_t rb_accumulate;
 } fn_conv_desc;
 
 int fn_conv2d_fwd(const fn_conv_desc* d, void* stream);

@@ -13,10 +13,32 @@ def _q(x, dt):
     return x + (x.to(dt).to(torch.float32) - x).detach()
 
 
+class _ReluWithMask(torch.autograd.Function):
+    """ReLU whose active set is GIVEN (the device path's): forward x*mask, backward grad*mask.  Two implementations of the
+    same forward differ by rounding noise eps, so a fraction ~eps of the pre-activations lands on the other side of zero;
+    every such element changes the gradient by its full magnitude and the relative gradient distance is ~sqrt(eps) -- a
+    property of ReLU, not an error of either side.  Sharing the masks removes it and leaves the backward ARITHMETIC."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return x * mask
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * mask, None
+
+
 class QuantOracle(fo.Oracle):
-    def __init__(self, params, dt, **kw):
+    def __init__(self, params, dt, masks=None, **kw):
         super().__init__(params, **kw)
         self.dt = dt
+        self.masks = masks or {}          # layer / block prefix -> float {0,1} tensor [N,C,H,W]: ReLU active sets to use
+
+    def _relu(self, x, prefix):
+        m = self.masks.get(prefix)
+        return F.relu(x) if m is None else _ReluWithMask.apply(x, m)
 
     def _conv(self, x, prefix, spec, bias=False):
         w = _q(self.p[prefix + "/kernel"], self.dt).permute(3, 2, 0, 1)
@@ -38,10 +60,15 @@ class QuantOracle(fo.Oracle):
             mean, var = self.p[prefix + "/bn/moving_mean"], self.p[prefix + "/bn/moving_variance"]
         yq = _q(y, self.dt)
         z = (yq - mean.view(1, -1, 1, 1)) * torch.rsqrt(var.view(1, -1, 1, 1) + fo.BN_EPS) + self.p[prefix + "/bn/beta"].view(1, -1, 1, 1)
-        return _q(F.relu(z), self.dt)
+        return _q(self._relu(z, prefix), self.dt)
 
     def _block(self, net, prefix, blk, scale, activation, training):
-        return _q(super()._block(net, prefix, blk, scale, activation, training), self.dt)
+        mixed = torch.cat([self._tower(net, f"{prefix}/tower_conv{i}", t, training) for i, t in enumerate(blk["towers"])], dim=1)
+        up = self._conv(mixed, prefix + "/up", fo._cbr("Conv2d_1x1", blk["up"], 1), bias=True)
+        net = net + scale * up
+        if activation:
+            net = self._relu(net, prefix)
+        return _q(net, self.dt)
 
     def forward(self, images, training=False, preprocessed=False):
         x = fo.image_processing(images, self.normalization, self.image_size)

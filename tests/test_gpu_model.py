@@ -195,16 +195,22 @@ def test_scheduled_multistream_step_matches_serial_replay():
         assert d[3] <= 3 * floor[3] + 2.5e-2                 # one Adam step moves a weight by at most ~lr
 
 
-def test_normalise_on_load_plan_matches_materialised_plan(monkeypatch):
-    """The optional plan that never writes the BN+ReLU tensors (consumers normalise the raw tensor while staging it) must
-    reproduce the default plan's step up to the run-to-run noise floor; it launches 78 fewer bn_relu_fwd kernels."""
+def test_lazy_and_virtual_batchnorm_plans_match_the_materialised_plan(monkeypatch):
+    """Three lowerings of the training forward must agree up to the run-to-run noise floor (fp32 atomics):
+      materialised : every BN+ReLU output written by fn_bn_relu_train_fwd (FACENET_LAZY_BN_MAXHW=0);
+      lazy (option) : on the <= 17x17 maps the single reader of a BN+ReLU output normalises the raw tensor while staging it
+                     and writes the activated tensor once (fn_conv_desc.nrm_z) -- 70 fewer launches;
+      virtual      : FACENET_NORM_ON_LOAD=1, the activated tensors are never written (78 fewer launches).
+    For the lazy plan every side-written tensor is also checked element by element against relu(raw*scale + shift) with the
+    scale / shift fn_bn_finalize published in the same run: each element written exactly once, none skipped."""
     from tests.util import structured_images
     E, N = 128, 6
     params, _, _ = fo.build_params(E, seed=0)
     x = torch.from_numpy(structured_images(N, seed=7))
     results, launches = [], []
-    for mode in ("0", "0", "1"):
-        monkeypatch.setenv("FACENET_NORM_ON_LOAD", mode)
+    for mode in ("mat", "mat", "lazy", "virtual"):
+        monkeypatch.setenv("FACENET_NORM_ON_LOAD", "1" if mode == "virtual" else "0")
+        monkeypatch.setenv("FACENET_LAZY_BN_MAXHW", "0" if mode == "mat" else "17")
         net = Network(embedding_size=E, device="cuda:0", train_dtype=torch.float16)
         net.load_keras_params(params)
         tr = Trainer(net, batch=N, loss="triplet", alpha=0.2, lr=0.01)
@@ -213,13 +219,27 @@ def test_normalise_on_load_plan_matches_materialised_plan(monkeypatch):
         torch.cuda.synchronize()
         results.append((tr.loss_value(), tr.emb.clone(), tr.G.clone(), net.P.clone(), net.S_mean.clone(), net.S_var.clone()))
         launches.append(sum(1 for op in tr.plan.fwd if op.name.startswith("bn_relu_fwd")))
-        assert bool(tr.plan.virtual) == (mode == "1")
-    assert launches[0] - launches[2] == 78 and any(op.name == "bn_finalize" for op in tr.plan.fwd)
+        assert bool(tr.plan.virtual) == (mode == "virtual") and bool(tr.plan.lazy) == (mode == "lazy")
+        if mode == "lazy":
+            assert any(op.name == "bn_finalize" for op in tr.plan.fwd)
+            checked = 0
+            for name, ranges in tr.plan.lazy.items():
+                b = tr.plan.bufs[name]
+                for (c0, Cc) in ranges:
+                    o = b.bn_off + c0
+                    sc, sh = tr.plan.save_scale[o:o + Cc].cpu(), tr.plan.save_shift[o:o + Cc].cpu()
+                    want = torch.relu(b.raw[..., c0:c0 + Cc].float().cpu() * sc + sh)
+                    got = b.act[..., c0:c0 + Cc].float().cpu()
+                    assert torch.allclose(got, want, rtol=2e-3, atol=1e-3), (name, c0, float((got - want).abs().max()))
+                    checked += 1
+            assert checked == 70
+    assert launches[0] - launches[2] == 70 and launches[0] - launches[3] == 78
     floor = (_rel(results[1][1], results[0][1]), _rel(results[1][2], results[0][2]))
-    d = (_rel(results[2][1], results[0][1]), _rel(results[2][2], results[0][2]))
-    print("noise floor (emb, grad):", floor, " normalise-on-load vs default:", d)
-    assert d[0] <= 3 * floor[0] + 2e-3 and d[1] <= 3 * floor[1] + 2e-2
-    assert torch.allclose(results[2][4], results[0][4], rtol=1e-3, atol=1e-4) and torch.allclose(results[2][5], results[0][5], rtol=1e-3, atol=1e-4)
+    for which in (2, 3):
+        d = (_rel(results[which][1], results[0][1]), _rel(results[which][2], results[0][2]))
+        print("noise floor (emb, grad):", floor, f" plan {which} vs materialised:", d)
+        assert d[0] <= 3 * floor[0] + 2e-3 and d[1] <= 3 * floor[1] + 2e-2
+        assert torch.allclose(results[which][4], results[0][4], rtol=1e-3, atol=1e-4) and torch.allclose(results[which][5], results[0][5], rtol=1e-3, atol=1e-4)
 
 
 def test_autotuned_plan_matches_heuristic_plan(monkeypatch, tmp_path):

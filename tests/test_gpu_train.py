@@ -179,30 +179,35 @@ TRUNC = {"block35": {"repeat": 1, "scale": 0.17, "activation": "relu"},
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_truncated_network_gradients_at_batch_45(dt):
-    """A well-conditioned whole-model gradient check: stem + 1 x Block35 + ReductionA + ReductionB + the last Block8 + head
-    at batch 45 (15 triplets).  At this batch the BatchNorm backward no longer amplifies storage rounding (see
-    test_gpu_model.py for batch 9), so the bar is absolute: cosine with the fp32 oracle >= 0.995 (bf16) / 0.9995 (f16) over
-    all parameters, and the HIP path no further from fp32 than 1.25 x the ideal storage-rounding model."""
-    from tests.quant_oracle import QuantOracle
-    E, N = 128, 45
-    params, trainable, _ = fo.build_params(E, seed=0, config=TRUNC)
+    """Whole-model gradient check on a shortened network: stem + 1 x Block35 + ReductionA + ReductionB + the last Block8 + head
+    + the softmax classifier (apps/train_softmax.py:49-104) at batch 45, against three references: the fp32 oracle, the
+    storage-rounding model (tests/quant_oracle.py) and the storage-rounding model on the device's ReLU active sets.
+    Measured: the rounding model itself sits at cosine 0.993 (f16) / 0.950 (bf16) from fp32 -- 16-bit activations flip the
+    sign of near-zero pre-activations, and no implementation with that storage gets closer -- so the HIP path is held to
+    "as good as the rounding model" against fp32 and to cosine >= 0.9995 against the rounding model once the active sets are
+    shared (what remains there is the backward arithmetic)."""
+    from tests.quant_oracle import QuantOracle, _q
+    E, N, NC = 128, 45, 37
+    params, trainable, _ = fo.build_params(E, seed=0, config=TRUNC, nrof_classes=NC)
     x = structured_images(N, seed=9)
-    x[2::3] = x[1::3]                                                   # negative = positive: every triplet is active
-    loss_ref, _, g32, _, emb_ref = fo.train_step_grads(params, trainable, [], x, "triplet", alpha=0.2, config=TRUNC)
+    labels = np.random.default_rng(5).integers(0, NC, N)
+    loss_ref, _, g32, _, emb_ref = fo.train_step_grads(params, trainable, [], x, "softmax", labels=labels, config=TRUNC)
     # storage-rounding model
     for k in trainable:
         params[k].requires_grad_(True)
         params[k].grad = None
     qo = QuantOracle(params, dt, config=TRUNC)
-    fo.triplet_loss(fo.l2_normalize(qo.forward(x, training=True)), 0.2).backward()
+    emb_q = qo.forward(x, training=True)
+    logits = _q(emb_q, dt) @ _q(params["classifier/logits/kernel"], dt) + params["classifier/logits/bias"]
+    fo.softmax_cross_entropy(logits, torch.as_tensor(labels)).backward()
     gq = {k: params[k].grad.detach().clone() for k in trainable}
     for k in trainable:
         params[k].requires_grad_(False)
         params[k].grad = None
-    net = Network(embedding_size=E, device="cuda:0", train_dtype=dt, config=TRUNC)
+    net = Network(embedding_size=E, device="cuda:0", train_dtype=dt, config=TRUNC, nrof_classes=NC)
     net.load_keras_params(params)
-    tr = Trainer(net, batch=N, loss="triplet", alpha=0.2, l2=0.0)
-    tr.set_images(torch.from_numpy(x))
+    tr = Trainer(net, batch=N, loss="softmax", l2=0.0)
+    tr.set_images(torch.from_numpy(x), torch.from_numpy(labels))
     st = net.stream()
     tr._zero()
     for ops in (tr.plan.fwd, tr.loss_ops, tr.plan.bwd):
@@ -211,12 +216,35 @@ def test_truncated_network_gradients_at_batch_45(dt):
     mine = net.export_keras_grads(tr.G)
     keys = [k for k in trainable if g32[k].norm() > 1e-6]
     flat = lambda d: torch.cat([d[k].reshape(-1).double() for k in keys])
-    cos = torch.nn.functional.cosine_similarity(flat(mine), flat(g32), dim=0).item()
-    cos_q = torch.nn.functional.cosine_similarity(flat(gq), flat(g32), dim=0).item()
-    rel = (flat(mine) - flat(g32)).norm().item() / flat(g32).norm().item()
-    rel_q = (flat(gq) - flat(g32)).norm().item() / flat(g32).norm().item()
-    print(f"{dt}: loss {tr.loss_value():.5f} (fp32 {loss_ref:.5f}); cosine HIP-fp32 {cos:.5f} (rounding model {cos_q:.5f}); "
-          f"rel err {rel:.4f} (rounding model {rel_q:.4f})")
-    assert abs(tr.loss_value() - loss_ref) < 2e-3
-    assert cos >= (0.9995 if dt == torch.float16 else 0.995)
-    assert rel <= 1.25 * rel_q + 0.01
+    cosine = lambda a, b: torch.nn.functional.cosine_similarity(flat(a), flat(b), dim=0).item()
+    relerr = lambda a, b: (flat(a) - flat(b)).norm().item() / flat(b).norm().item()
+    # third reference: the rounding model evaluated on the DEVICE's ReLU active sets (quant_oracle._ReluWithMask): what is left
+    # between it and the HIP path is arithmetic, not the sign of near-zero pre-activations
+    masks = {}
+    for r in tr.plan.recs:
+        if r.kind == "conv" and r.extra.get("kind") == "bn":
+            masks[r.layer.name] = (r.y.buf.act[..., r.y.c0:r.y.c0 + r.y.C] > 0).float().cpu().permute(0, 3, 1, 2).contiguous()
+        elif r.kind == "conv" and r.extra.get("kind") == "resid" and r.extra["relu"]:
+            masks[r.layer.name[:-3]] = (r.y.buf.act > 0).float().cpu().permute(0, 3, 1, 2).contiguous()
+    for k in trainable:
+        params[k].requires_grad_(True)
+        params[k].grad = None
+    qm = QuantOracle(params, dt, masks=masks, config=TRUNC)
+    logits = _q(qm.forward(x, training=True), dt) @ _q(params["classifier/logits/kernel"], dt) + params["classifier/logits/bias"]
+    fo.softmax_cross_entropy(logits, torch.as_tensor(labels)).backward()
+    gm = {k: params[k].grad.detach().clone() for k in trainable}
+    for k in trainable:
+        params[k].requires_grad_(False)
+        params[k].grad = None
+    cos, cos_q, cos_m = cosine(mine, g32), cosine(gq, g32), cosine(mine, gm)
+    rel, rel_q, rel_m = relerr(mine, g32), relerr(gq, g32), relerr(mine, gm)
+    print(f"{dt}: loss {tr.loss_value():.5f} (fp32 {loss_ref:.5f}); cosine HIP-fp32 {cos:.5f} (rounding model-fp32 {cos_q:.5f}), HIP-rounding "
+          f"model on device masks {cos_m:.6f}; rel err {rel:.4f} ({rel_q:.4f}), {rel_m:.4f}")
+    f16 = dt == torch.float16
+    assert abs(tr.loss_value() - loss_ref) < (2e-3 if f16 else 2e-2)
+    # against fp32 nobody storing activations in 16 bits can do better than the rounding model: ReLU sign flips of near-zero
+    # pre-activations put it at cosine 0.993 (f16) / 0.95 (bf16) even at this batch.  The HIP path must be as good ...
+    assert cos >= cos_q - 0.003 and rel <= 1.1 * rel_q + 0.01
+    assert cos >= (0.99 if f16 else 0.94)
+    # ... and, with the active sets shared, agree with the rounding model tightly
+    assert cos_m >= (0.99995 if f16 else 0.9995) and rel_m <= (1e-2 if f16 else 3e-2)
