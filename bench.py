@@ -87,6 +87,33 @@ def time_ops_individually(ops, stream, lib, reps=3, burst=4):
     return [max((t / reps - ovh) / burst, 1e-4) for t in sums]
 
 
+def time_ops_insitu(ops, stream, lib, reps=5, prepare=None):
+    """IN-STEP per-launch durations: the whole step is replayed eagerly in program order with ONE event pair around every
+    launch (events on the stream the kernels run on), `reps` times; returns the per-launch MEDIAN in milliseconds, net of the
+    empty event-pair overhead.  Operands are as cold / warm as the preceding launches of the step leave them and every launch
+    waits for its real predecessor -- this is the duration rocprofv3 --kernel-trace reports for the same launch, unlike a
+    burst of identical back-to-back launches (time_ops_individually), which runs L2-warm."""
+    from facenet_amd import _lib
+    per = [[] for _ in ops]
+    for _ in range(reps):
+        if prepare is not None:
+            prepare()
+        evs = []
+        for op in ops:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = op.fn(*op.args, stream)
+            if rc:
+                _lib.check(rc, op.name)
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(evs):
+            per[i].append(a.elapsed_time(b))
+    ovh = event_pair_overhead_ms()
+    return [max(float(np.median(t)) - ovh, 1e-4) for t in per]
+
+
 def _mangle_hint(demangled):
     """rocprofv3 reports demangled names: rebuild the template-argument part in mangled spelling for one matcher."""
     import re
@@ -97,11 +124,28 @@ def _mangle_hint(demangled):
     return f"{m.group(1)}I{'DF16b' if m.group(2) == '__bf16' else 'DF16_'}{args}E"
 
 
-def pmc_traffic(kernel_key):
-    """HBM bytes per launch of one conv instantiation from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-    profiles/r01_pmc_hbm_traffic.json); None when the profile is absent."""
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+
+
+def tile_signature(*tile_dicts):
+    """Identifies the kernel variants a run launches (the autotuner's choices): PMC counters cannot be read inside this
+    process, so `roofline.traffic` is only quoted from the committed rocprofv3 passes when THAT run used the same tiles."""
+    import hashlib
+    h = hashlib.sha1()
+    for d in tile_dicts:
+        for k in sorted(d):
+            h.update(f"{k}={d[k]};".encode())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_key, signature):
+    """HBM bytes per launch of one conv instantiation from the committed rocprofv3 PMC passes (separate --pmc passes,
+    FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes; tools/pmc_dump.py); None when the profile is absent or was
+    taken with other tile choices than this run's."""
     import re
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    path = PMC_PROFILE
+    if os.path.exists(path) and json.load(open(path)).get("tile_signature") != signature:
+        return None
     m = re.match(r"(conv_igemm_kernel|conv_igemm_grouped_kernel|conv_wgrad_kernel|conv_wgrad_grouped_kernel)"
                  r"<(__bf16|_Float16),(\d+),(\d+)(?:,ks=(\d))?(?:,1x1=(\d))?>", kernel_key)
     if not (m and os.path.exists(path)):
@@ -119,7 +163,7 @@ def pmc_traffic(kernel_key):
     return round(tot / n) if n else None
 
 
-def kernel_roofline(trainer, miner, lib, dump=None):
+def kernel_roofline(trainer, miner, lib, dump=None, signature=None):
     """Attribute event-timed launches to kernel instantiations; report the dominant one against its roofline."""
     import ctypes as C
     net = trainer.net
@@ -128,9 +172,11 @@ def kernel_roofline(trainer, miner, lib, dump=None):
     all_ops = list(miner.ops) + [op for op in trainer.step_ops if not getattr(op.fn, "_torch_op", False)]
     trainer._zero()
     torch.cuda.synchronize()
-    t = time_ops_individually(all_ops, st, lib)
+    t_burst = time_ops_individually(all_ops, st, lib)
+    t = time_ops_insitu(all_ops, st, lib, prepare=trainer._zero)
+    burst_of = {}
     per_op = []
-    for op, ms in zip(all_ops, t):
+    for op, ms, msb in zip(all_ops, t, t_burst):
         kind = op.name.split(":")[0]
         if kind in ("conv_fwd_grouped", "conv_dgrad_grouped"):
             descs = op.keep[0]
@@ -163,6 +209,8 @@ def kernel_roofline(trainer, miner, lib, dump=None):
             plain = int(d.KH == 1 and d.KW == 1 and d.stride == 1 and d.pad_h == 0 and d.pad_w == 0)
             if opi == 2:
                 key = f"conv_wgrad_kernel<{tname},{v // 1000},{v % 1000}>"
+            elif v >= 9000000:
+                key = f"conv_halo_kernel<{tname},BN={v % 1000},3x3>"
             else:
                 ks = f",ks={v // 1000000}" if v >= 1000000 else ""
                 key = f"conv_igemm_kernel<{tname},{v % 1000000 // 1000},{v % 1000}{ks},1x1={plain}>"
@@ -176,7 +224,9 @@ def kernel_roofline(trainer, miner, lib, dump=None):
             g = groups.setdefault(kind, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, bound="hbm"))
             per_op.append(dict(op=op.name, us=round(ms * 1e3, 2)))
         g["ms"] += ms
+        g["ms_burst"] = g.get("ms_burst", 0.0) + msb
         g["launches"] += 1
+        per_op[-1]["us_burst"] = round(msb * 1e3, 2)
     if dump:
         with open(dump, "w") as f:
             json.dump(per_op, f, indent=0)
@@ -192,8 +242,10 @@ def kernel_roofline(trainer, miner, lib, dump=None):
     hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
     first, other = (hbm, mfma) if hbm["frac"] > mfma["frac"] else (mfma, hbm)
     roof = {
-        **first, "kernel": name, "traffic": pmc_traffic(name),
+        **first, "kernel": name, "traffic": pmc_traffic(name, signature),
+        "timing": "in-step: one HIP-event pair per launch over an eager replay of the whole step, median of 5 passes",
         "launches_per_step": g["launches"], "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
+        "avg_launch_us_warm_burst": round(1e3 * g.get("ms_burst", 0.0) / g["launches"], 2),
         "share_of_step_kernel_time": round(g["ms"] / total_ms, 3),
         "flop_per_launch_avg": round(g["flops"] / g["launches"], 0), "algorithmic_bytes_per_launch_avg": round(g["bytes"] / g["launches"], 0),
         "other_roofline": other,
@@ -204,9 +256,10 @@ def kernel_roofline(trainer, miner, lib, dump=None):
     return roof, breakdown, total_ms
 
 
-def cpu_baseline(pool_n=60, batch=30, E=128, reps=2):
-    """The oracle (a port: PyTorch-CPU fp32 restatement) timed on this box's host cores on a bounded sample of the same
-    workload: mining forward over a 60-image pool + one 30-image (10 triplets) train step incl. Keras Adam."""
+def cpu_baseline(pool_n=180, batch=90, E=128, reps=3):
+    """The oracle (a port: PyTorch-CPU fp32 restatement) timed on this box's host cores on the SAME workload as the GPU step
+    (BASELINE.json configs[1]): mining forward over the 45x4 = 180 image pool + distance matrix + selection + one 90-image
+    (30 triplets) train step incl. Keras Adam; 1 warm-up + `reps` timed steps."""
     from oracle import facenet_oracle as fo
     params, trainable, regularized = fo.build_params(E, seed=0)
     rng = np.random.default_rng(0)
@@ -230,17 +283,45 @@ def cpu_baseline(pool_n=60, batch=30, E=128, reps=2):
         one()
     dt = (time.perf_counter() - t0) / reps
     return {"value": round(batch / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{reps} steps of (mining forward {pool_n} images + triplet train step on {batch} images), fp32 PyTorch-CPU oracle, "
-                      f"{dt:.2f} s/step, host has {os.cpu_count()} logical cores"}
+            "sample": f"1 warm-up + {reps} timed steps of the full workload (mining forward {pool_n} images + selection + triplet train step on "
+                      f"{batch} images + Keras Adam), fp32 PyTorch-CPU oracle, {dt:.2f} s/step, host has {os.cpu_count()} logical cores"}
+
+
+def embedding_l2_err(dev):
+    """BASELINE.json metric, second half ("LFW embedding L2 err"; no LFW images exist here): max row L2 distance
+    between the GPU path's unit-norm embeddings and the CPU oracle's on BASELINE.json configs[0] -- 16 seeded random uint8
+    images, E=128, fresh and perturbed BatchNorm statistics -- for both storage types.  north_star bound: 1e-3."""
+    from facenet_amd.engine import Network
+    from oracle import facenet_oracle as fo
+    x = np.random.default_rng(0).integers(0, 256, (16, 160, 160, 3), dtype=np.uint8)
+    out = {}
+    for variant in ("fresh", "perturbed"):
+        params, _, _ = fo.build_params(128, seed=0)
+        if variant == "perturbed":
+            fo.perturb_bn_stats(params, seed=1)
+        ref = fo.Oracle(params).forward(x, training=False)
+        for name, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+            net = Network(embedding_size=128, device=str(dev), infer_dtype=dt)
+            net.load_keras_params(params)
+            plan = net.plan(16, training=False)
+            plan.images.copy_(torch.from_numpy(x))
+            plan.run_forward()
+            torch.cuda.synchronize()
+            emb = fo.l2_normalize(plan.embedding.buf.act.view(16, 128).float().cpu())
+            out[f"{name}_{variant}"] = float(f"{(emb - ref).norm(dim=1).max().item():.3e}")
+    out["note"] = ("max row L2 distance to the fp32 CPU oracle, 16 random 160x160 images (BASELINE.json configs[0]); the inference / mining "
+                   "path stores activations in f16 (bound 1e-3 met), bf16 storage is the training dtype and is shown for reference")
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)      # SURVEY.md 8d: 20 warm-up + 100 timed steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="replay the launch list eagerly instead of through HIP graphs")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (oracle timing and embedding error)")
+    ap.add_argument("--cpu-sample", action="store_true", help="time the CPU oracle on a third of the workload (60-image pool + 30-image step)")
     ap.add_argument("--batch", type=int, default=90)
     ap.add_argument("--pool", type=int, default=180)
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the dependency scheduler may use (1 = serial)")
@@ -350,12 +431,25 @@ def main():
             "model_tflops": round((3 * B + POOL) * FWD_GFLOP_PER_IMAGE * 1e-3 / (ms * 1e-3), 1),
         }
     if rank == 0 and world == 1:
-        roof, breakdown, kernel_ms = kernel_roofline(trainer, miner, lib, args.dump_ops)
+        sig = tile_signature(trainer.tiles, miner.tiles)
+        roof, breakdown, kernel_ms = kernel_roofline(trainer, miner, lib, args.dump_ops, sig)
         out["roofline"] = roof
         out["kernel_breakdown"] = breakdown
-        out["sum_kernel_ms_eager"] = round(kernel_ms, 3)
+        out["sum_kernel_ms_insitu"] = round(kernel_ms, 3)
+        out["launches_per_step"] = len(miner.ops) + len([op for op in trainer.step_ops])
+        out["tile_signature"] = sig
+        # whole-step rooflines (SURVEY.md 8d / BASELINE.md section 2): algorithmic work of one step against the chip's peaks
+        step_flop = (3 * B + POOL) * FWD_GFLOP_PER_IMAGE * 1e9
+        step_bytes = POOL * 12.4e6 + B * 30.8e6 + 0.82e9
+        out["step_roofline"] = {
+            "flop": step_flop, "lower_bound_bytes": step_bytes,
+            "mfma_frac": round(step_flop / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "hbm_frac": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "lower_bound_ms": round(1e3 * max(step_flop / (MFMA_PEAK_TFLOPS * 1e12), step_bytes / (HBM_PEAK_GBS * 1e9)), 3),
+            "note": "forward 2.802 GFLOP/img x (180 mined + 3 x 90 trained); bytes = 12.4 MB/img mining + 30.8 MB/img training + 0.82 GB parameters"}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["embedding_l2_err"] = embedding_l2_err(dev)
+            out["cpu_baseline"] = cpu_baseline(60, 30, reps=2) if args.cpu_sample else cpu_baseline()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -73,6 +73,7 @@ struct ConvArgs {
     float nrm_eps;
     unsigned short* nrm_z;    // optional: the normalised operand is also written here (geometry of src), see fn_conv_desc.nrm_z
     // dgrad epilogue: fused residual backward (fn_conv_desc.rb_*).  `resid` (scale 1) carries rb_prev, `out` is rb_dtrunk.
+    int halo_ty, halo_tx;         // halo kernel: 8x16-pixel output tiles per image (rows, columns)
     const unsigned short* mask;   // rows of the block's forward output: values <= 0 zero the gradient
     unsigned short* out2;         // scale2 * (masked gradient), geometry of out
     float* colsum;                // += column sums of what goes to out2
@@ -101,6 +102,193 @@ __device__ __forceinline__ int ktab_entry(int kgroup, int KTOT, int CS, int KW) 
     rcp_divmod(k, CS, tap, c);
     rcp_divmod(tap, KW, ky, kx);
     return (ky << 24) | (kx << 16) | c;
+}
+
+// Epilogue of every forward / data-gradient convolution kernel: the fp32 accumulators go through LDS (C tile) so that global
+// stores are full 16-byte rows, and everything that touches the output once is fused here: bias, residual scale-add, ReLU
+// (or the ReLU mask of a fused residual backward), accumulate, BatchNorm batch statistics, the BatchNorm-backward reduction
+// of the producing layer, channel-slice output.  Tile rows map to output pixels either linearly (m0 + row < a.M) or through
+// the row table sRow (-1 = no pixel): the parity classes of a stride-2 data gradient and the 2-D tiles of the halo kernel.
+// `active`: threads 0..255 of the group that owns the accumulators; every thread of the workgroup must call (barriers).
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], unsigned char* smem, float* sRed,
+                                              const int* sRow, const bool rowtab, const int m0, const int n0, const int tm, const bool active) {
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MREP = TM / 16, NREP = TN / 16;
+    constexpr int CLD = BN + 4;
+    float* sC = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid & 255) >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    if (a.stats && active) {  // BatchNorm batch statistics from the fp32 accumulators (rows >= M are exact zeros)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[i][j][r];
+                    s += v;
+                    q += v * v;
+                }
+            s += __shfl_xor(s, 16);
+            q += __shfl_xor(q, 16);
+            s += __shfl_xor(s, 32);
+            q += __shfl_xor(q, 32);
+            if (lane < 16) {
+                atomicAdd(&sRed[wn * TN + j * 16 + lane], s);
+                atomicAdd(&sRed[BN + wn * TN + j * 16 + lane], q);
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sC[(wm * TM + i * 16 + fq * 4 + r) * CLD + wn * TN + j * 16 + fr] = acc[i][j][r];
+    }
+    __syncthreads();
+
+    constexpr int CG = BN / 8, RP = 256 / CG;
+    const int cg = tid % CG, rr = tid / CG;
+    const int col = n0 + cg * 8;
+    float bq1[8], bq2[8];   // fused BN-backward partial sums of this thread's 8 columns
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bq1[e] = 0.f; bq2[e] = 0.f; }
+    if (active && col < a.NOUT) {
+        float bnsc[8], bnsf[8], bnbt[8];
+        if (a.bn_y) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bnsc[e] = a.bn_scale[col + e]; bnsf[e] = a.bn_shift[col + e]; bnbt[e] = a.bn_beta[col + e]; }
+        }
+        float bias[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias[e] = (a.bias && col + e < a.NOUT) ? a.bias[col + e] : 0.f;
+        const bool full = (col + 8 <= a.NOUT);
+#pragma unroll
+        for (int ps = 0; ps < (BM + RP - 1) / RP; ++ps) {
+            const int row = ps * RP + rr;
+            if (row >= BM) continue;
+            int m = m0 + row;
+            if (rowtab) {
+                m = sRow[row];
+                if (m < 0) continue;
+            } else if (m >= a.M) {
+                continue;
+            }
+            float v[8];
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(&sC[row * CLD + cg * 8]);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(&sC[row * CLD + cg * 8 + 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = c0[e] + bias[e];
+                v[4 + e] = c1[e] + bias[4 + e];
+            }
+            if (a.resid) {
+                float rv[8];
+                unpack8<T>(*reinterpret_cast<const u32x4*>(a.resid + (long)m * a.ld_res + col), rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = rv[e] + a.scale * v[e];
+            }
+            const long o = (long)m * a.ld_out + col;
+            if (a.mask) {   // fused residual backward: ReLU mask of the block output, then the scaled copy for the `up` branch
+                float mk[8];
+                unpack8<T>(*reinterpret_cast<const u32x4*>(a.mask + o), mk);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+            }
+            if (a.out2) {
+                float u[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { u[e] = a.scale2 * v[e]; bq1[e] += u[e]; }
+                *reinterpret_cast<u32x4*>(a.out2 + o) = pack8<T>(u);
+            }
+            if (a.bn_y) {   // dgrad only (no resid/relu/f32 here): v is the complete gradient unless accumulating
+                float yy[8], tot[8];
+                unpack8<T>(*reinterpret_cast<const u32x4*>(a.bn_y + (long)m * a.ld_bn_y + col), yy);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    tot[e] = v[e];
+                    const float zf = fmaf(yy[e], bnsc[e], bnsf[e]);
+                    const float gg = (!a.bn_relu || zf > 0.f) ? tot[e] : 0.f;
+                    bq1[e] += gg;
+                    bq2[e] += gg * (zf - bnbt[e]);
+                }
+            }
+            if (a.out_f32) {
+                float* op = reinterpret_cast<float*>(a.out) + o;
+                if (full && !a.accumulate) {
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
+                    for (int e = 0; e < 8 && col + e < a.NOUT; ++e) {
+                        float x = v[e] + (a.accumulate ? op[e] : 0.f);
+                        op[e] = a.relu ? fmaxf(x, 0.f) : x;
+                    }
+                }
+            } else {
+                unsigned short* op = reinterpret_cast<unsigned short*>(a.out) + o;
+                if (full) {
+                    if (a.accumulate) {
+                        float pv[8];
+                        unpack8<T>(*reinterpret_cast<const u32x4*>(op), pv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += pv[e];
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    *reinterpret_cast<u32x4*>(op) = pack8<T>(v);
+                } else {
+                    for (int e = 0; e < 8 && col + e < a.NOUT; ++e) {
+                        float x = v[e] + (a.accumulate ? LP<T>::to_f32(op[e]) : 0.f);
+                        op[e] = LP<T>::from_f32(a.relu ? fmaxf(x, 0.f) : x);
+                    }
+                }
+            }
+        }
+    }
+    if (a.bn_y || a.out2) {   // fold the RP row lanes through LDS (the C tile is no longer needed), one atomic per column per block
+        __syncthreads();
+        float* sP = reinterpret_cast<float*>(smem);   // [RP][2*BN]
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sP[rr * 2 * BN + cg * 8 + e] = bq1[e];
+                sP[rr * 2 * BN + BN + cg * 8 + e] = bq2[e];
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int c = tid < BN ? tid : tid - BN;
+            if (n0 + c < a.NOUT) {
+                float sum = 0.f;
+#pragma unroll 8
+                for (int t = 0; t < RP; ++t) sum += sP[t * 2 * BN + tid];
+                if (a.out2) {
+                    if (tid < BN) atomicAdd(&a.colsum[n0 + c], sum);
+                } else {
+                    float* ap = a.bn_acc + (long)(tm % a.bn_replicas) * a.bn_rep_stride + (tid < BN ? 0 : a.bn_sq_off);
+                    atomicAdd(&ap[n0 + c], sum);
+                }
+            }
+        }
+    }
+    if (a.stats && tid < BN && n0 + tid < a.NOUT) {
+        // global float atomics to one address serialise at the memory side: spread the row tiles over replicas
+        float* sp = a.stats + (long)(tm % a.stats_replicas) * a.stats_rep_stride;
+        atomicAdd(&sp[n0 + tid], sRed[tid]);
+        atomicAdd(&sp[a.stats_sq_off + n0 + tid], sRed[BN + tid]);
+    }
 }
 
 // KS > 1: in-launch split-K.  The workgroup has KS groups of 256 threads; group g multiplies k tiles g, g+KS, .. with its own
@@ -449,176 +637,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     }
     const bool active = grp == 0;   // group 0 owns the epilogue; the others only keep the barriers company
 
-    // ---- epilogue -------------------------------------------------------------------------------
-    if (a.stats && active) {  // BatchNorm batch statistics from the fp32 accumulators (rows >= M are exact zeros)
-#pragma unroll
-        for (int j = 0; j < NREP; ++j) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int i = 0; i < MREP; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc[i][j][r];
-                    s += v;
-                    q += v * v;
-                }
-            s += __shfl_xor(s, 16);
-            q += __shfl_xor(q, 16);
-            s += __shfl_xor(s, 32);
-            q += __shfl_xor(q, 32);
-            if (lane < 16) {
-                atomicAdd(&sRed[wn * TN + j * 16 + lane], s);
-                atomicAdd(&sRed[BN + wn * TN + j * 16 + lane], q);
-            }
-        }
-    }
-    if (active) {
-#pragma unroll
-        for (int i = 0; i < MREP; ++i)
-#pragma unroll
-            for (int j = 0; j < NREP; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    sC[(wm * TM + i * 16 + fq * 4 + r) * CLD + wn * TN + j * 16 + fr] = acc[i][j][r];
-    }
-    __syncthreads();
-
-    constexpr int CG = BN / 8, RP = 256 / CG;
-    const int cg = tid % CG, rr = tid / CG;
-    const int col = n0 + cg * 8;
-    float bq1[8], bq2[8];   // fused BN-backward partial sums of this thread's 8 columns
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { bq1[e] = 0.f; bq2[e] = 0.f; }
-    if (active && col < a.NOUT) {
-        float bnsc[8], bnsf[8], bnbt[8];
-        if (a.bn_y) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { bnsc[e] = a.bn_scale[col + e]; bnsf[e] = a.bn_shift[col + e]; bnbt[e] = a.bn_beta[col + e]; }
-        }
-        float bias[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bias[e] = (a.bias && col + e < a.NOUT) ? a.bias[col + e] : 0.f;
-        const bool full = (col + 8 <= a.NOUT);
-#pragma unroll
-        for (int ps = 0; ps < (BM + RP - 1) / RP; ++ps) {
-            const int row = ps * RP + rr;
-            if (row >= BM) continue;
-            int m = m0 + row;
-            if (!PLAIN && a.s2) {
-                m = sRow[row];
-                if (m < 0) continue;
-            } else if (m >= a.M) {
-                continue;
-            }
-            float v[8];
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(&sC[row * CLD + cg * 8]);
-            const f32x4 c1 = *reinterpret_cast<const f32x4*>(&sC[row * CLD + cg * 8 + 4]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = c0[e] + bias[e];
-                v[4 + e] = c1[e] + bias[4 + e];
-            }
-            if (a.resid) {
-                float rv[8];
-                unpack8<T>(*reinterpret_cast<const u32x4*>(a.resid + (long)m * a.ld_res + col), rv);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = rv[e] + a.scale * v[e];
-            }
-            const long o = (long)m * a.ld_out + col;
-            if (a.mask) {   // fused residual backward: ReLU mask of the block output, then the scaled copy for the `up` branch
-                float mk[8];
-                unpack8<T>(*reinterpret_cast<const u32x4*>(a.mask + o), mk);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
-            }
-            if (a.out2) {
-                float u[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { u[e] = a.scale2 * v[e]; bq1[e] += u[e]; }
-                *reinterpret_cast<u32x4*>(a.out2 + o) = pack8<T>(u);
-            }
-            if (a.bn_y) {   // dgrad only (no resid/relu/f32 here): v is the complete gradient unless accumulating
-                float yy[8], tot[8];
-                unpack8<T>(*reinterpret_cast<const u32x4*>(a.bn_y + (long)m * a.ld_bn_y + col), yy);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    tot[e] = v[e];
-                    const float zf = fmaf(yy[e], bnsc[e], bnsf[e]);
-                    const float gg = (!a.bn_relu || zf > 0.f) ? tot[e] : 0.f;
-                    bq1[e] += gg;
-                    bq2[e] += gg * (zf - bnbt[e]);
-                }
-            }
-            if (a.out_f32) {
-                float* op = reinterpret_cast<float*>(a.out) + o;
-                if (full && !a.accumulate) {
-                    if (a.relu) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                } else {
-                    for (int e = 0; e < 8 && col + e < a.NOUT; ++e) {
-                        float x = v[e] + (a.accumulate ? op[e] : 0.f);
-                        op[e] = a.relu ? fmaxf(x, 0.f) : x;
-                    }
-                }
-            } else {
-                unsigned short* op = reinterpret_cast<unsigned short*>(a.out) + o;
-                if (full) {
-                    if (a.accumulate) {
-                        float pv[8];
-                        unpack8<T>(*reinterpret_cast<const u32x4*>(op), pv);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += pv[e];
-                    }
-                    if (a.relu) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    *reinterpret_cast<u32x4*>(op) = pack8<T>(v);
-                } else {
-                    for (int e = 0; e < 8 && col + e < a.NOUT; ++e) {
-                        float x = v[e] + (a.accumulate ? LP<T>::to_f32(op[e]) : 0.f);
-                        op[e] = LP<T>::from_f32(a.relu ? fmaxf(x, 0.f) : x);
-                    }
-                }
-            }
-        }
-    }
-    if (a.bn_y || a.out2) {   // fold the RP row lanes through LDS (the C tile is no longer needed), one atomic per column per block
-        __syncthreads();
-        float* sP = reinterpret_cast<float*>(smem);   // [RP][2*BN]
-        if (active) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                sP[rr * 2 * BN + cg * 8 + e] = bq1[e];
-                sP[rr * 2 * BN + BN + cg * 8 + e] = bq2[e];
-            }
-        }
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int c = tid < BN ? tid : tid - BN;
-            if (n0 + c < a.NOUT) {
-                float sum = 0.f;
-#pragma unroll 8
-                for (int t = 0; t < RP; ++t) sum += sP[t * 2 * BN + tid];
-                if (a.out2) {
-                    if (tid < BN) atomicAdd(&a.colsum[n0 + c], sum);
-                } else {
-                    float* ap = a.bn_acc + (long)(tm % a.bn_replicas) * a.bn_rep_stride + (tid < BN ? 0 : a.bn_sq_off);
-                    atomicAdd(&ap[n0 + c], sum);
-                }
-            }
-        }
-    }
-    if (a.stats && tid < BN && n0 + tid < a.NOUT) {
-        // global float atomics to one address serialise at the memory side: spread the row tiles over replicas
-        float* sp = a.stats + (long)(tm % a.stats_replicas) * a.stats_rep_stride;
-        atomicAdd(&sp[n0 + tid], sRed[tid]);
-        atomicAdd(&sp[a.stats_sq_off + n0 + tid], sRed[BN + tid]);
-    }
+    // ---- epilogue (shared with the halo kernel) -----------------------------------------------------
+    conv_epilogue<T, BM, BN, WM, WN>(a, acc, smem, sRed, sRow, !PLAIN && a.s2, m0, n0, tm, active);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, int MODE>
@@ -636,6 +656,204 @@ __global__ __launch_bounds__(256 * KS) void conv_igemm_grouped_kernel(const Conv
     g = __builtin_amdgcn_readfirstlane(g);             // provably wave-uniform: args[g] is fetched with scalar loads into SGPRs
     const ConvArgs a = args[g];
     conv_igemm_body<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, MODE>(a, bid - prefix[g]);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Halo-tile convolution: stride-1 k x k layers on the large maps (stem 3x3 layers, forward and data gradient).
+//
+// The implicit-GEMM kernel above gathers every tap of every output pixel from global memory: a 3x3 layer moves each input
+// element nine times from L2 to the CU, and on the 35^2 .. 79^2 maps that traffic (~64 B/clk/CU of L2 bandwidth), not the
+// MFMA pipe, sets the time (Conv2d_2a/2b: 240-370 TFLOP/s).  Here a workgroup owns an 8 x 16 pixel output tile of one image
+// and BN output channels: per 32-channel slice of the input it loads the (8+KH-1) x (16+KW-1) pixel source patch ONCE
+// (64 B per pixel, hardware zero fill outside the map) and the BN x taps x 32 weights into LDS, and forms all KH*KW taps from
+// LDS: the A fragment of tile row `py` at tap (dy, dx) is the 1 KiB run of 16 consecutive patch pixels starting at
+// (py + dy) * PW + dx.  Rows are 64 B with the 16-byte slot XOR-ed by ((row >> 2) & 1) << 1, which makes every such run --
+// at ANY start pixel -- conflict free for ds_read_b128's lane groups (brute-forced against MI355X_MICROARCH.md's table).
+// One MFMA 16x16x32 consumes a whole 32-channel slice per tap; the next slice's loads are issued before the current slice
+// is multiplied (issue early / write late).  The data gradient is the same kernel with the taps mirrored (sk = -1) and the
+// transposed weight pack.  The epilogue is conv_epilogue (row table: tile pixel -> output pixel).
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename T, int BN, int WM, int WN, int KH, int KW>
+__global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a) {
+    constexpr int TH = 8, TW = 16, BM = TH * TW;
+    constexpr int TM = BM / WM, TN = BN / WN, MREP = TM / 16, NREP = TN / 16;
+    constexpr int PHt = TH + KH - 1, PWt = TW + KW - 1, NPIX = PHt * PWt, TAPS = KH * KW;
+    constexpr int PATCH_BYTES = (NPIX * 64 + 255) / 256 * 256;
+    constexpr int WROWS = TAPS * BN;
+    constexpr int W_BYTES = WROWS * 64;
+    constexpr int STAGE_BYTES = PATCH_BYTES + W_BYTES;
+    constexpr int C_BYTES = BM * (BN + 4) * 4;
+    constexpr int MAIN_BYTES = STAGE_BYTES > C_BYTES ? STAGE_BYTES : C_BYTES;
+    constexpr int NPL = (NPIX * 4 + 255) / 256;      // 16-byte patch chunks per thread
+    constexpr int NWL = (WROWS * 4 + 255) / 256;     // 16-byte weight chunks per thread
+    typedef typename LP<T>::vec8 vec8;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sP = smem;
+    unsigned char* sW = smem + PATCH_BYTES;
+    float* sRed = reinterpret_cast<float*>(smem + MAIN_BYTES);
+    int* sRow = reinterpret_cast<int*>(smem + MAIN_BYTES + 2 * BN * 4);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // tile -> (image, tile row, tile column, column tile); the column tile varies fastest: workgroups that share a patch are neighbours
+    const int tiles_n = a.tiles_n;
+    const int t = xcd_remap(blockIdx.x, a.total_tiles);
+    int sp, tn, n, rem, ty, tx;
+    rcp_divmod(t, tiles_n, sp, tn);
+    rcp_divmod(sp, a.halo_ty * a.halo_tx, n, rem);
+    rcp_divmod(rem, a.halo_tx, ty, tx);
+    const int oy0 = ty * TH, ox0 = tx * TW, n0 = tn * BN;
+    // source coordinates of patch pixel (0,0): forward taps run down/right (sk = +1), mirrored for the data gradient
+    const int sy0 = oy0 + a.offy - (a.sk > 0 ? 0 : KH - 1), sx0 = ox0 + a.offx - (a.sk > 0 ? 0 : KW - 1);
+
+    if (tid < 2 * BN) sRed[tid] = 0.f;
+    if (tid < BM) {
+        const int py = tid >> 4, px = tid & 15;
+        sRow[tid] = (oy0 + py < a.PH && ox0 + px < a.PW) ? (n * a.PH + oy0 + py) * a.PW + ox0 + px : -1;
+    }
+
+    constexpr unsigned OOB = 0x60000000u;
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.src), 0, a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, a.w_bytes, 0x00020000);
+    // per-thread load slots: byte offset at channel 0 (or OOB) and the LDS byte address, fixed for the whole kernel
+    unsigned poff[NPL], woff[NWL];
+    int plds[NPL], wlds[NWL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int idx = tid + 256 * i, p = idx >> 2, ch = idx & 3;
+        const int pr = p / PWt, pc = p - pr * PWt;
+        const int sy = sy0 + pr, sx = sx0 + pc;
+        const bool ok = p < NPIX && (unsigned)sy < (unsigned)a.SH && (unsigned)sx < (unsigned)a.SW;
+        poff[i] = ok ? (unsigned)(((n * a.SH + sy) * a.SW + sx) * a.ld_src + ch * 8) * 2u : OOB;
+        plds[i] = p < NPIX ? p * 64 + ((ch ^ (((p >> 2) & 1) << 1)) << 4) : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < NWL; ++j) {
+        const int idx = tid + 256 * j, rw = idx >> 2, ch = idx & 3;
+        const int tap = rw / BN, co = rw - tap * BN;
+        const bool ok = rw < WROWS && n0 + co < a.NOUT;
+        woff[j] = ok ? (unsigned)((n0 + co) * a.KTOT + tap * a.CS + ch * 8) * 2u : OOB;
+        wlds[j] = rw < WROWS ? rw * 64 + ((ch ^ (((rw >> 2) & 1) << 1)) << 4) : -1;
+    }
+
+    u32x4 rp[NPL], rw_[NWL];
+    auto load_slice = [&](int c0) {      // 32 input channels starting at c0; channel groups beyond CS read zeros
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int ch = (tid + 256 * i) & 3;
+            const unsigned off = (c0 + ch * 8 < a.CS) ? poff[i] + (unsigned)c0 * 2u : OOB;
+            rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, (int)off, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NWL; ++j) {
+            const int ch = (tid + 256 * j) & 3;
+            const unsigned off = (c0 + ch * 8 < a.CS) ? woff[j] + (unsigned)c0 * 2u : OOB;
+            rw_[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)off, 0, 0);
+        }
+    };
+    auto store_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPL; ++i)
+            if (plds[i] >= 0) *reinterpret_cast<u32x4*>(sP + plds[i]) = rp[i];
+#pragma unroll
+        for (int j = 0; j < NWL; ++j)
+            if (wlds[j] >= 0) *reinterpret_cast<u32x4*>(sW + wlds[j]) = rw_[j];
+    };
+
+    f32x4 acc[MREP][NREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nslices = (a.CS + 31) >> 5;
+    load_slice(0);
+    for (int sl = 0; sl < nslices; ++sl) {
+        __syncthreads();                     // everybody is done reading the previous slice
+        store_slice();
+        __syncthreads();
+        if (nslices > 1) load_slice(min(sl + 1, nslices - 1) * 32);     // uniform condition; within a multi-slice loop unconditional (clamped)
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = tap / KW, kx = tap - ky * KW;
+            const int pdy = a.sk > 0 ? ky : KH - 1 - ky, pdx = a.sk > 0 ? kx : KW - 1 - kx;
+            vec8 fa[MREP], fb[NREP];
+#pragma unroll
+            for (int i = 0; i < MREP; ++i) {
+                const int pix = (wm * (TM / 16) + i + pdy) * PWt + fr + pdx;       // tile row wm*TM/16 + i, 16 pixels of it
+                fa[i] = *reinterpret_cast<const vec8*>(sP + pix * 64 + ((fq ^ (((pix >> 2) & 1) << 1)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) {
+                const int rw = tap * BN + wn * TN + j * 16 + fr;
+                fb[j] = *reinterpret_cast<const vec8*>(sW + rw * 64 + ((fq ^ (((rw >> 2) & 1) << 1)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) acc[i][j] = LP<T>::mfma(fa[i], fb[j], acc[i][j]);
+        }
+    }
+    // tile pixels outside the output map were computed from real source pixels: zero them, the statistics in the epilogue sum
+    // whole accumulator columns (C layout: row = 4 * (lane >> 4) + register = pixel column, tile row = row fragment)
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const bool row_ok = oy0 + wm * MREP + i < a.PH;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = row_ok && ox0 + fq * 4 + r < a.PW;
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) acc[i][j][r] = ok ? acc[i][j][r] : 0.f;
+        }
+    }
+    __syncthreads();        // the C tile overlays the staging buffers
+    conv_epilogue<T, BM, BN, WM, WN>(a, acc, smem, sRed, sRow, true, 0, n0, sp, true);
+}
+
+static size_t halo_smem_bytes(int BN, int KH, int KW) {
+    const int npix = (8 + KH - 1) * (16 + KW - 1);
+    const int stage = (npix * 64 + 255) / 256 * 256 + KH * KW * BN * 64;
+    const int cb = 128 * (BN + 4) * 4;
+    return (size_t)(stage > cb ? stage : cb) + 2 * BN * 4 + 128 * 4;
+}
+
+// which layers go to the halo kernel: stride-1 3x3 (forward or data gradient) on maps of at least 30 x 30 output pixels with at
+// most FN_CONV_HALO_MAXC (64) source channels, plain operand (no normalise-on-load / sibling sources).  Measured on MI355X
+// (tools/dev_convbench.py halo, batch 90 / 180): Conv2d_2a 53 -> 35 / 89 -> 55 us, Conv2d_2b 61 -> 54 / 108 -> 93 us; Conv2d_4a
+// (80 -> 192 channels on 35 x 35: 36 % of the 8x16 tile slots fall outside the map and the weights are re-staged per slice) is
+// slower here (79 vs 65 us) and stays on the implicit-GEMM kernel.  FN_CONV_HALO=0 switches the kernel off (A/B measurements).
+static bool halo_eligible(const ConvArgs& a) {
+    static const int enabled = getenv("FN_CONV_HALO") ? atoi(getenv("FN_CONV_HALO")) : 1;
+    static const int maxc = getenv("FN_CONV_HALO_MAXC") ? atoi(getenv("FN_CONV_HALO_MAXC")) : 64;
+    return enabled && !a.s2 && !a.plain && a.so == 1 && a.dshift == 0 && a.KH == 3 && a.KW == 3 && a.CS % 8 == 0 && a.CS <= maxc && a.PH >= 30 && a.PW >= 30 &&
+           !a.nrm_stats && a.nt_total == 0 && a.tile == 0;   // an explicit tile (fn_conv_desc.tile_*) asks for the implicit-GEMM kernel
+}
+static int halo_bn(const ConvArgs& a) { return a.NOUT <= 32 ? 32 : (a.NOUT <= 48 || (a.NOUT > 64 && a.NOUT <= 96) ? 32 : 64); }
+
+template <typename T, int BN, int WM, int WN, int KH, int KW> static int launch_halo_p(ConvArgs a, hipStream_t st) {
+    a.halo_ty = cdiv(a.PH, 8);
+    a.halo_tx = cdiv(a.PW, 16);
+    a.tiles_n = cdiv(a.NOUT, BN);
+    a.tiles_m = 0;
+    const long total = (long)(a.M / (a.PH * a.PW)) * a.halo_ty * a.halo_tx * a.tiles_n;
+    FN_REQUIRE(total < (1L << 24), "conv_halo: too many tiles");
+    a.total_tiles = (int)total;
+    const size_t smem = halo_smem_bytes(BN, KH, KW);
+    auto kern = conv_halo_kernel<T, BN, WM, WN, KH, KW>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.total_tiles), dim3(256), smem, st, a);
+    return check_launch("conv_halo");
+}
+
+template <typename T> static int launch_halo(const ConvArgs& a, hipStream_t st) {
+    return halo_bn(a) == 32 ? launch_halo_p<T, 32, 4, 1, 3, 3>(a, st) : launch_halo_p<T, 64, 2, 2, 3, 3>(a, st);
 }
 
 // tiles of a launch; in class mode (stride-2 dgrad) every parity class has its own row tiles
@@ -766,6 +984,7 @@ static int choose_conv_ks(int M, int NOUT, int KTOT, int bm, int bn) {
 static int variant_code(int bm, int bn, int ks) { return bm * 1000 + bn + (ks > 1 ? ks * 1000000 : 0); }
 
 template <typename T> static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
+    if (halo_eligible(a)) return launch_halo<T>(a, st);
     int bm, bn;
     choose_conv_tile(a.M, a.NOUT, a.tile, bm, bn);
     if (const char* f = getenv("FN_CONV_TILE")) {   // tuning aid: "BMxBN"
@@ -1399,6 +1618,10 @@ extern "C" int fn_conv2d_wgrad_grouped(const void* dev_args, const int32_t* dev_
 extern "C" int fn_conv2d_variant(const fn_conv_desc* d, int op) {
     if (!d || op < 0 || op > 2) return FN_EINVAL;
     int a, b;
+    if (op < 2) {   // halo-tile kernel: 9000000 + BN (never grouped, never re-tiled)
+        ConvArgs ca;
+        if ((op == 0 ? make_fwd_args(d, ca) : make_dgrad_args(d, ca)) == FN_OK && halo_eligible(ca)) return 9000000 + halo_bn(ca);
+    }
     if (op == 0) {
         choose_conv_tile(d->N * d->OH * d->OW, d->Cout, valid_tile(d->tile_fwd) ? d->tile_fwd : 0, a, b);
         return variant_code(a, b, d->nrm_stats ? 1 : choose_conv_ks(d->N * d->OH * d->OW, d->Cout, d->KH * d->KW * d->Cin, a, b));

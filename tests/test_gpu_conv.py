@@ -27,7 +27,28 @@ CASES = [
     (5, 3, 3, 192, 192, 3, 1, 1, 1, 0),    # block8 3x1
     (5, 3, 3, 384, 1792, 1, 1, 1, 0, 0),   # block8 up
     (7, 1, 1, 1792, 128, 1, 1, 1, 0, 0),   # Dense 1792 -> E
+    # halo-tile kernel (stride-1 3x3 on maps >= 30x30): ragged 8x16 tiles, partial 32-channel slices, both column-tile widths
+    (2, 37, 37, 80, 192, 3, 3, 1, 0, 0),   # 4a at full map size (Cin=80: the third slice is half empty; dgrad: Cout tile 32 x 3)
+    (2, 40, 33, 32, 64, 3, 3, 1, 1, 1),    # 'same' padding: zero fill on all four sides
+    (1, 45, 39, 32, 32, 3, 3, 1, 0, 0),    # 2a-like: 32-wide column tile
+    (2, 35, 35, 192, 80, 3, 3, 1, 0, 0),   # Cout=80 (three 32-wide column tiles, the last half empty), six input slices
 ]
+HALO_CASES = CASES[-4:]
+
+
+def test_halo_cases_dispatch_to_the_halo_kernel(lib):
+    """The cases above are there to exercise conv_halo_kernel: fn_conv2d_variant reports 9000000 + BN for them (forward and
+    data gradient), and an explicit tile sends the same layer to the implicit-GEMM kernel."""
+    for (N, H, W, Cin, Cout, kh, kw, s, ph, pw) in HALO_CASES:
+        d = conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, _lib.FN_BF16)
+        t = torch.zeros(16, device="cuda")
+        d.x = d.w = d.y = d.dx = ptr(t)
+        assert lib.fn_conv2d_variant(C.byref(d), 0) >= 9000000 and lib.fn_conv2d_variant(C.byref(d), 1) >= 9000000
+        d.tile_fwd = d.tile_dgrad = 64064
+        assert lib.fn_conv2d_variant(C.byref(d), 0) == 64064 and lib.fn_conv2d_variant(C.byref(d), 1) == 64064
+    d = conv_desc(2, 17, 17, 32, 32, 3, 3, 1, 1, 1, _lib.FN_BF16)          # small map: implicit GEMM
+    d.x = d.w = d.y = d.dx = ptr(torch.zeros(16, device="cuda"))
+    assert lib.fn_conv2d_variant(C.byref(d), 0) < 9000000
 
 
 def _mk(shape, dt, scale=1.0, seed=0):
@@ -189,10 +210,11 @@ def test_conv_wgrad_grouped_matches_single_launches(lib):
 
 
 @pytest.mark.parametrize("dt", [_lib.FN_BF16, _lib.FN_F16])
-def test_dgrad_fused_bn_backward_reduction(lib, dt):
+@pytest.mark.parametrize("H", [17, 37])           # 37: the halo-tile kernel runs the same shared epilogue
+def test_dgrad_fused_bn_backward_reduction(lib, dt, H):
     """dgrad epilogue computing sum(dyh) / sum(dyh*xhat) of the producing layer's BatchNorm (+ReLU) == the standalone
     reduce kernel; the apply kernel then consumes the replicated accumulators."""
-    N, H, W, Cin, Cout = 3, 17, 17, 64, 96
+    N, W, Cin, Cout = 3, H, 64, 96
     d = conv_desc(N, H, W, Cin, Cout, 3, 3, 1, 1, 1, dt)
     M = N * H * W
     dy = _mk((N, H, W, Cout), dt, seed=51)
