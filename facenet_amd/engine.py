@@ -478,7 +478,7 @@ class Lowering:
         # Optional (FACENET_LAZY_BN_MAXHW=17; default 0 = off): on maps up to that size a BN+ReLU output with exactly ONE reader, a
         # stride-1 convolution whose output map has the input's size, is materialised BY that reader -- it normalises the raw
         # tensor while staging its operand and the workgroups of its first column tile write the activated tensor once, at the
-        # centre tap (fn_conv_desc.nrm_z); the weight gradient and the backward pass read the same buffers as before.  70 of the
+        # centre tap (fn_conv_desc.nrm_z); the weight gradient and the backward pass read the same buffers as before.  68 of the
         # 82 fn_bn_relu_train_fwd launches disappear, but the step does not get faster (MI355X, batch 90: 7.58-7.60 ms with,
         # 7.54 ms without): normalise-on-load costs each reader 2.5-4.5 us (tools/dev_normcost.py: a dependent statistics round
         # trip in the prologue plus ~40 VALU instructions per 16-byte chunk on the load -> LDS path of a latency-bound k loop,
@@ -492,6 +492,9 @@ class Lowering:
         # gradient of block i+1 (fn_conv_desc.rb_*).  18 of the 21 fn_residual_bwd launches and one read-modify-write pass over
         # every block output's gradient disappear.
         self.fuse_residual_bwd = bool(int(os.environ.get("FACENET_FUSE_RESIDUAL_BWD", "1")))
+        # Inference / mining plans: a whole Block17 (five convolution launches) runs as ONE launch with its tower activations in
+        # LDS (fn_block17_infer, csrc/block_fused.hip).  BatchNorm is folded there, so nothing couples the images of a batch.
+        self.fuse_blocks = bool(int(os.environ.get("FACENET_FUSE_BLOCKS", "1")))
         self.virtual: Dict[str, List[Tuple[int, int]]] = {}     # buffer -> [(c0, C)] BN ranges that are not materialised
         self.dtype = net.train_dtype if training else net.infer_dtype
         self.dt = None if declare else _lib.dtype_code(self.dtype)
@@ -598,6 +601,12 @@ class Lowering:
         """Block35/17/8 (:83-259): towers -> concat -> up 1x1 (+bias) -> act(trunk + scale*up)."""
         H, W = trunk.buf.H, trunk.buf.W
         cm = sum(t[-1][1] for t in towers)
+        if (not self.declare and not self.training and self.fuse_blocks and (H, W, up) == (8, 8, 896) and towers == BLOCK_TOWERS["block17"][0]
+                and trunk.c0 == 0 and trunk.C == trunk.buf.C == 896):
+            out = self.buf(prefix + "/out", H, W, up)
+            self.readers[trunk.buf.name] = self.readers.get(trunk.buf.name, 0) + 1
+            self.recs.append(Rec("block17", None, trunk, out.full(), dict(prefix=prefix, scale=float(scale), relu=bool(relu))))
+            return out.full()
         mixed = self.buf(prefix + "/mixed", H, W, cm, bn_channels=cm, need_raw=True)
         c0 = 0
         for i, t in enumerate(towers):
@@ -843,6 +852,17 @@ class Lowering:
                 d.bias = _ptr(net.P, L.bias_off)
             writes.append((tgt.act.data_ptr(), r.y.c0, r.y.c0 + r.y.C))
         self._emit(self.fwd, "conv_fwd:" + L.name, lib.fn_conv2d_fwd, C.byref(d), keep=(d,), r=reads, w=writes)
+
+    def _fwd_block17(self, r: Rec):
+        net, pre = self.net, r.extra["prefix"]
+        Ls = [net.layers[f"{pre}/{n}"] for n in ("tower_conv0/Conv2d_1x1", "tower_conv1/Conv2d_0a_1x1", "tower_conv1/Conv2d_0b_1x7",
+                                                 "tower_conv1/Conv2d_0c_7x1", "up")]
+        ws = [_ptr(net.W_infer, L.w_off) for L in Ls]
+        bs = [_ptr(net.fold_bias, L.bn_off) for L in Ls[:4]] + [_ptr(net.P, Ls[4].bias_off)]
+        reads = [self._ra(r.x)] + [region(net.W_infer, L.w_off, L.w_off + L.numel) for L in Ls] + \
+                [region(net.fold_bias, L.bn_off, L.bn_off + L.cout) for L in Ls[:4]] + [region(net.P, Ls[4].bias_off, Ls[4].bias_off + Ls[4].cout)]
+        self._emit(self.fwd, "block17_fused:" + pre, net.lib.fn_block17_infer, _ptr(r.x.buf.act), _ptr(r.y.buf.act), self.N, *ws, *bs,
+                   r.extra["scale"], 1 if r.extra["relu"] else 0, self.dt, r=reads, w=[self._ra(r.y)])
 
     def _fwd_bn(self, r: Rec):
         if not self.training:

@@ -109,6 +109,14 @@ typedef struct fn_conv_desc {
     int32_t rb_accumulate;
 } fn_conv_desc;
 
+/* One Inception-ResNet-B block ("Block17", inception_resnet_v1.py:153-204) of the BN-FOLDED inference network in ONE launch:
+ * 1x1 | 1x1 -> 1x7 -> 7x1 towers, concat, `up` 1x1 + bias, scaled residual add, ReLU.  One workgroup per image; the tower
+ * activations stay in LDS, only weights stream (csrc/block_fused.hip).  x, y: [N,8,8,896] low precision (x != y); weights: the
+ * inference packs [Cout][taps][Cin] of the five layers (fn_fold_bn); b_t*: the folded BatchNorm shifts, b_up: the `up` bias.
+ * Equals the five fn_conv2d_fwd launches it replaces up to the summation order. */
+int fn_block17_infer(const void* x, void* y, int N, const void* w_t0, const void* w_t1a, const void* w_t1b, const void* w_t1c, const void* w_up,
+                     const float* b_t0, const float* b_t1a, const float* b_t1b, const float* b_t1c, const float* b_up, float scale, int relu,
+                     int dtype, void* stream);
 int fn_conv2d_fwd(const fn_conv_desc* d, void* stream);
 int fn_conv2d_dgrad(const fn_conv_desc* d, void* stream);
 int fn_conv2d_wgrad(const fn_conv_desc* d, void* stream);

@@ -199,7 +199,8 @@ def test_lazy_and_virtual_batchnorm_plans_match_the_materialised_plan(monkeypatc
     """Three lowerings of the training forward must agree up to the run-to-run noise floor (fp32 atomics):
       materialised : every BN+ReLU output written by fn_bn_relu_train_fwd (FACENET_LAZY_BN_MAXHW=0);
       lazy (option) : on the <= 17x17 maps the single reader of a BN+ReLU output normalises the raw tensor while staging it
-                     and writes the activated tensor once (fn_conv_desc.nrm_z) -- 70 fewer launches;
+                     and writes the activated tensor once (fn_conv_desc.nrm_z) -- 68 fewer launches (readers with more than 1024 K
+                     columns, the two big 3x3 layers of the reduction blocks, keep the separate pass);
       virtual      : FACENET_NORM_ON_LOAD=1, the activated tensors are never written (78 fewer launches).
     For the lazy plan every side-written tensor is also checked element by element against relu(raw*scale + shift) with the
     scale / shift fn_bn_finalize published in the same run: each element written exactly once, none skipped."""
@@ -232,8 +233,8 @@ def test_lazy_and_virtual_batchnorm_plans_match_the_materialised_plan(monkeypatc
                     got = b.act[..., c0:c0 + Cc].float().cpu()
                     assert torch.allclose(got, want, rtol=2e-3, atol=1e-3), (name, c0, float((got - want).abs().max()))
                     checked += 1
-            assert checked == 70
-    assert launches[0] - launches[2] == 70 and launches[0] - launches[3] == 78
+            assert checked == 68
+    assert launches[0] - launches[2] == 68 and launches[0] - launches[3] == 78
     floor = (_rel(results[1][1], results[0][1]), _rel(results[1][2], results[0][2]))
     for which in (2, 3):
         d = (_rel(results[which][1], results[0][1]), _rel(results[which][2], results[0][2]))
@@ -263,7 +264,9 @@ def test_autotuned_plan_matches_heuristic_plan(monkeypatch, tmp_path):
         torch.cuda.synchronize()
         results.append((tr.emb.clone(), tr.G.clone()))
         tiles.append(dict(tr.tiles))
-    assert tiles[0] == {} and len(tiles[2]) > 200 and all(t // 1000 in (128, 64, 32) and t % 1000 in (128, 64, 32) for t in tiles[2].values())
+    # 0 = the library's own choice won (only offered where that is the halo-tile kernel, which competes with the nine tiles)
+    assert tiles[0] == {} and len(tiles[2]) > 200 and all(t == 0 or (t // 1000 in (128, 64, 32) and t % 1000 in (128, 64, 32)) for t in tiles[2].values())
+    assert all(t != 0 or "conv2d/Conv2d_2" in k for k, t in tiles[2].items())
     assert tiles[3] == tiles[2] and cache.is_file()                    # second tuned trainer: read back, not re-timed
     floor = (_rel(results[1][0], results[0][0]), _rel(results[1][1], results[0][1]))
     for r in results[2:]:
