@@ -325,6 +325,7 @@ def main():
     ap.add_argument("--batch", type=int, default=90)
     ap.add_argument("--pool", type=int, default=180)
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the dependency scheduler may use (1 = serial)")
+    ap.add_argument("--force-segments", action="store_true", help="1 GPU: run the data-parallel segment structure (6 buckets) without the all-reduce")
     ap.add_argument("--dump-ops", default=None, help="write per-launch HIP-event timings (eager) to this JSON file")
     args = ap.parse_args()
 
@@ -357,7 +358,8 @@ def main():
 
     E, B, POOL = 128, args.batch, args.pool
     net = Network(embedding_size=E, device=str(dev), train_dtype=torch.bfloat16, infer_dtype=torch.float16, seed=0)
-    trainer = Trainer(net, batch=B, loss="triplet", alpha=0.2, lr=0.05, world_size=world, process_group=pg, n_streams=args.streams)
+    trainer = Trainer(net, batch=B, loss="triplet", alpha=0.2, lr=0.05, world_size=world, process_group=pg, n_streams=args.streams,
+                      force_segments=args.force_segments)
     labels = np.repeat(np.arange(POOL // 4), 4)
     miner = TripletMiner(net, POOL, labels, B // 3, alpha=0.2, seed=1000 * rank, n_streams=args.streams)
     miner.build(trainer.plan.images)

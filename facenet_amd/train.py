@@ -223,8 +223,11 @@ def _streams_for(net: Network, n_streams: int) -> StreamSet:
 class Trainer:
     def __init__(self, net: Network, batch: int, loss: str = "triplet", alpha: float = 0.2, lr: float = 0.05, beta1: float = 0.9,
                  beta2: float = 0.999, epsilon: float = 0.1, l2: float = L2_WEIGHT, world_size: int = 1, process_group=None,
-                 n_buckets: int = 6, n_streams: int = 1, group_wgrad: bool = True):
+                 n_buckets: int = 6, n_streams: int = 1, group_wgrad: bool = True, force_segments: bool = False):
         self.group_wgrad = group_wgrad
+        # force_segments: a single replica runs the data-parallel step structure (backward cut at the bucket boundaries, one graph
+        # per segment, per-segment grouped weight gradients) with the all-reduce left out: what the segmentation alone costs
+        self.segmented = world_size > 1 or force_segments
         if loss not in ("triplet", "softmax"):
             raise ValueError(f"unknown loss {loss!r}")
         if loss == "triplet" and batch % 3:
@@ -310,7 +313,7 @@ class Trainer:
                  r=[region(self.G), region(self.hyper)], w=[region(net.P), region(self.M), region(self.V), region(net.W_train)])
         self._op(self.opt_ops, "pack_transpose", lib.fn_pack_transpose, _ptr(net.W_train), _ptr(net.Wt_train), _ptr(net.table),
                  len(net.layers), net.max_layer_elems, self.dt, r=[region(net.W_train)], w=[region(net.Wt_train)])
-        self.buckets = self._make_buckets(n_buckets) if world_size > 1 else []
+        self.buckets = self._make_buckets(n_buckets) if self.segmented else []
         self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
         self.streams = _streams_for(net, n_streams)
         self.tiles = autotune_convs(self.plan.fwd + self.loss_ops + self.plan.bwd, net)
@@ -352,7 +355,7 @@ class Trainer:
         head = self.pre_ops + self.plan.fwd + self.loss_ops
         grp = (lambda ops: group_wgrads(group_convs(ops, self.net), self.net)) if self.group_wgrad else (lambda ops: list(ops))
         self.segments: List[Tuple[Optional[Schedule], Optional[Tuple[int, int]]]] = []
-        if self.world == 1:
+        if not self.segmented:
             self.segments.append((Schedule(grp(head + self.plan.bwd) + self.opt_ops, self.n_streams), None))
             return
         pos, first = 0, True
@@ -381,8 +384,13 @@ class Trainer:
 
     def _run_segments(self, launch: Callable[[int], None]):
         self.net.folded_valid = False        # parameters and moving statistics are about to change
-        if self.world == 1:
+        if not self.segmented:
             launch(0)
+            return
+        if self.world == 1:                   # force_segments: the segment structure without the exchange
+            for i, (sched, _) in enumerate(self.segments):
+                if sched is not None:
+                    launch(i)
             return
         cur = torch.cuda.current_stream(self.net.device)
         for i, (sched, rng) in enumerate(self.segments[:-1]):
@@ -407,8 +415,9 @@ class Trainer:
         ROCm 7.0/7.2 note (measured on MI355X): ending a capture whose fork/join pattern spans 3 or more streams
         segfaults inside hipStreamEndCapture, while 2 streams capture and replay correctly -- schedules wider than 2
         streams are therefore re-placed on 2 streams for the captured path (eager replay keeps the requested width)."""
-        if self.n_streams > 2:
-            self.n_streams = 2
+        max_streams = int(os.environ.get("FACENET_CAPTURE_MAX_STREAMS", "2"))     # > 2 only to investigate the note above
+        if self.n_streams > max_streams:
+            self.n_streams = max_streams
             self._build_segments()
         # The warm-up below is a full training step on whatever the image buffer holds.  Training state is snapshotted and
         # restored around it, so capture() followed by n steps equals n eager steps (Adam's t, the moving statistics and the

@@ -266,7 +266,7 @@ def test_autotuned_plan_matches_heuristic_plan(monkeypatch, tmp_path):
         tiles.append(dict(tr.tiles))
     # 0 = the library's own choice won (only offered where that is the halo-tile kernel, which competes with the nine tiles)
     assert tiles[0] == {} and len(tiles[2]) > 200 and all(t == 0 or (t // 1000 in (128, 64, 32) and t % 1000 in (128, 64, 32)) for t in tiles[2].values())
-    assert all(t != 0 or "conv2d/Conv2d_2" in k for k, t in tiles[2].items())
+    assert all(t != 0 or "conv2d/Conv2d_" in k for k, t in tiles[2].items())            # only stem layers are halo-eligible
     assert tiles[3] == tiles[2] and cache.is_file()                    # second tuned trainer: read back, not re-timed
     floor = (_rel(results[1][0], results[0][0]), _rel(results[1][1], results[0][1]))
     for r in results[2:]:
