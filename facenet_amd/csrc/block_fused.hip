@@ -319,6 +319,246 @@ __global__ __launch_bounds__(512) void block17_infer_kernel(const Block17Args a)
 #undef SLAB_STORE
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Fused Inception-ResNet-A block ("Block35", inception_resnet_v1.py:83-150), BN-folded inference / mining forward:
+//     t0 = relu(1x1(x)), t1 = relu(3x3(relu(1x1(x)))), t2 = relu(3x3(relu(3x3(relu(1x1(x))))))        (256 -> 32 each, 32 -> 32)
+//     out = act(x + scale * (1x1(concat(t0, t1, t2), 96 -> 256) + bias))
+// The layer-by-layer plan moves the 17 x 17 x 256 trunk through HBM five times per block (three 1x1 readers, the residual, the
+// output) for 44 MFLOP per image; here the trunk is read twice (stage 1 stream, residual) and written once, everything else
+// stays in LDS.  One workgroup (8 waves) per image: 289 pixels = 19 row fragments, wave w owns fragments w, w+8, w+16 and ALL
+// columns of a stage (the stages are only 32 .. 96 columns wide).  Activations: 64-byte pixel rows per 32-channel slice
+// (swz64); the 3x3 inputs are kept as 19 x 19 patches with a 1-pixel zero halo, so the nine taps are nine shifted views.
+// The weights of a stage (<= 48 KB) are staged in LDS in one piece; only the trunk of stage 1 streams (ring pipeline).
+// ------------------------------------------------------------------------------------------------------------------------
+struct Block35Args {
+    const unsigned short* x;       // [N, 17, 17, 256]
+    unsigned short* y;
+    const unsigned short* w_1x1[3];   // tower_conv0/1x1, tower_conv1/0a, tower_conv2/0a: [32][256]
+    const unsigned short* w_3x3[3];   // tower_conv1/0b, tower_conv2/0b, tower_conv2/0c: [32][9][32]
+    const unsigned short* w_up;       // [256][96]
+    const float* b_1x1[3];
+    const float* b_3x3[3];
+    const float* b_up;
+    float scale;
+    int relu;
+    int N;
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) void block35_infer_kernel(const Block35Args a) {
+    constexpr int C = 256, NPIX = 289, MROWS = 304, D = 4;          // 19 row fragments
+    constexpr int SLICE_BYTES = MROWS * 64;                          // one 32-channel slice of the image (padded rows)
+    constexpr int PATCH_PIX = 19 * 19, PATCH_BYTES = (PATCH_PIX * 64 + 1023) / 1024 * 1024 + 1024;   // reads of padded rows stay inside
+    constexpr int MIXED_BYTES = 3 * SLICE_BYTES;                     // t0 | t1 | t2
+    constexpr int STAGE_BYTES = SLICE_BYTES + 96 * 64;               // stage 1: trunk slice + slab [96 columns][64 B]
+    typedef typename LP<T>::vec8 vec8;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sMixed = smem;
+    unsigned char* sP1 = sMixed + MIXED_BYTES;
+    unsigned char* sP2 = sP1 + PATCH_BYTES;
+    unsigned char* sStage = sP2 + PATCH_BYTES;            // [2][STAGE_BYTES]; later: the weights of a stage in one piece
+    float* sC = reinterpret_cast<float*>(sP1);            // stage 4: fp32 C tile [304][36] over the (dead) patches
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int img = blockIdx.x;
+    const unsigned short* xin = a.x + (long)img * NPIX * C;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xin), 0, NPIX * C * 2, 0x00020000);
+    constexpr unsigned OOB = 0x60000000u;
+
+    for (int i = tid; i < 2 * PATCH_BYTES / 16; i += 512) reinterpret_cast<u32x4*>(sP1)[i] = u32x4{0u, 0u, 0u, 0u};
+
+    // row fragments of this wave: f = wave + 8 i, i < 3, valid while f < 19 (wave-uniform)
+    const int nfr = wave < 3 ? 3 : 2;
+    int prow[3];          // first pixel of each fragment's lane (row = lane & 15)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) prow[i] = (wave + 8 * i) * 16 + fr;
+
+    // cooperative copy of a [rows][32 channels] weight block (64-byte rows in global, row stride `gstride` elements) into LDS
+    auto stage_weights = [&](unsigned char* dst, const unsigned short* w, int rows, int gstride, int goff) {
+        for (int i = tid; i < rows * 4; i += 512) {
+            const int r = i >> 2, ch = i & 3;
+            *reinterpret_cast<u32x4*>(dst + swz64(r, ch)) = load_global_b128(w, (long)r * gstride + goff + ch * 8);
+        }
+    };
+    // relu(acc + bias) -> LDS image: pixel p at index pidx(p) of `region` (slice base), channel c (0..31); C layout of the 16x16 MFMA
+    auto store_frag = [&](const f32x4& v, float bias, unsigned char* region, int frag, int col, bool patch) {
+        const int cc = col & 31;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = frag * 16 + fq * 4 + r;
+            if (p < NPIX) {
+                const int y = p / 17, x = p - y * 17;
+                const int pidx = patch ? (y + 1) * 19 + x + 1 : p;
+                *reinterpret_cast<unsigned short*>(region + swz64(pidx, cc >> 3) + (cc & 7) * 2) = LP<T>::from_f32(fmaxf(v[r] + bias, 0.f));
+            }
+        }
+    };
+
+    // ---------------- stage 1: [t0 | t1a | t2a] = relu(x[289 x 256] * W[256 x 96] + b): trunk slices stream, 8 k tiles of 32 channels ----------------
+    {
+        f32x4 acc[3][6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 ra[D][3], rb[D];
+        int voff_a[3], st_a[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int idx = tid + 512 * q, p = idx >> 2, ch = idx & 3;
+            voff_a[q] = p < NPIX ? (p * C + ch * 8) * 2 : (int)OOB;
+            st_a[q] = p < MROWS ? swz64(p, ch) : -1;
+        }
+        const int wr = tid >> 2, wch = tid & 3;                     // slab row (column of the stage) 0..95 for tid < 384
+        const unsigned short* wrow = a.w_1x1[min(wr >> 5, 2)] + (long)(wr & 31) * C + wch * 8;
+        const int st_b = wr < 96 ? SLICE_BYTES + swz64(wr, wch) : -1;
+#define S1_LOAD(kt, d)                                                                                     \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) ra[d][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff_a[q], (kt) * 64, 0); \
+        rb[d] = load_global_b128(wrow, (kt) * 32);
+#define S1_STORE(buf, d)                                                                                   \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                        \
+            if (st_a[q] >= 0) *reinterpret_cast<u32x4*>(sStage + (buf) * STAGE_BYTES + st_a[q]) = ra[d][q];  \
+        if (st_b >= 0) *reinterpret_cast<u32x4*>(sStage + (buf) * STAGE_BYTES + st_b) = rb[d];
+#define S1_COMPUTE(kt, buf, d)                                                                                           \
+        {                                                                                                                  \
+            const unsigned char* pa = sStage + (buf) * STAGE_BYTES;                                                        \
+            vec8 fb[6];                                                                                                    \
+            _Pragma("unroll") for (int j = 0; j < 6; ++j) fb[j] = *reinterpret_cast<const vec8*>(pa + SLICE_BYTES + swz64(j * 16 + fr, fq)); \
+            _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                                  \
+                if (i < nfr) {                                                                                             \
+                    const vec8 fa = *reinterpret_cast<const vec8*>(pa + swz64(prow[i], fq));                               \
+                    _Pragma("unroll") for (int j = 0; j < 6; ++j) acc[i][j] = LP<T>::mfma(fa, fb[j], acc[i][j]);           \
+                }                                                                                                          \
+        }
+        FN_RING_PIPELINE(D, C / 32, S1_LOAD, S1_STORE, S1_COMPUTE)
+#undef S1_LOAD
+#undef S1_STORE
+#undef S1_COMPUTE
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int col = j * 16 + fr, t = col >> 5;               // tower 0 -> mixed slice 0, towers 1, 2 -> patches P1, P2
+            const float bias = a.b_1x1[t][col & 31];
+            unsigned char* region = t == 0 ? sMixed : (t == 1 ? sP1 : sP2);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < nfr) store_frag(acc[i][j], bias, region, wave + 8 * i, col, t != 0);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- stages 2a, 2b, 3: 3x3 32 -> 32 from a 19 x 19 patch; weights [32][9][32] staged whole (18 KB) ----------------
+    int fa_tap[9][3];          // LDS offset of this lane's A fragment i at tap t
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int p = min(prow[i], NPIX - 1);                    // padding rows read a real pixel; their results are dropped
+            const int y = p / 17, x = p - y * 17;
+            fa_tap[t][i] = swz64((y + t / 3) * 19 + x + t % 3, fq);
+        }
+#pragma unroll 1
+    for (int c3 = 0; c3 < 3; ++c3) {
+        // c3 = 0: t1b = 3x3(P1) -> mixed slice 1; c3 = 1: t2b = 3x3(P2) -> P1 (its reader is done); c3 = 2: t2c = 3x3(P1) -> mixed slice 2
+        const unsigned char* src = c3 == 1 ? sP2 : sP1;
+        for (int i = tid; i < 9 * 32 * 4; i += 512) {                // slab rows = tap * 32 + column
+            const int r = i >> 2, ch = i & 3, tap = r >> 5, co = r & 31;
+            *reinterpret_cast<u32x4*>(sStage + swz64(r, ch)) = load_global_b128(a.w_3x3[c3], (long)co * 288 + tap * 32 + ch * 8);
+        }
+        __syncthreads();
+        f32x4 acc[3][2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            vec8 fb[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const vec8*>(sStage + swz64(t * 32 + j * 16 + fr, fq));
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < nfr) {
+                    const vec8 fa = *reinterpret_cast<const vec8*>(src + fa_tap[t][i]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = LP<T>::mfma(fa, fb[j], acc[i][j]);
+                }
+        }
+        __syncthreads();                                             // everybody is done reading src before P1 is overwritten (c3 = 1)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = j * 16 + fr;
+            const float bias = a.b_3x3[c3][col];
+            unsigned char* region = c3 == 0 ? sMixed + SLICE_BYTES : (c3 == 1 ? sP1 : sMixed + 2 * SLICE_BYTES);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < nfr) store_frag(acc[i][j], bias, region, wave + 8 * i, col, c3 == 1);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- stage 4: out = act(x + scale * (mixed[289 x 96] * Wup[96 x 256] + bias)); weights staged whole (48 KB), 8 passes of 32 columns ----------------
+    {
+        constexpr int CLD = 36;
+        for (int i = tid; i < 3 * 256 * 4; i += 512) {               // slab rows = slice * 256 + column
+            const int r = i >> 2, ch = i & 3, sl = r >> 8, co = r & 255;
+            *reinterpret_cast<u32x4*>(sStage + swz64(r, ch)) = load_global_b128(a.w_up, (long)co * 96 + sl * 32 + ch * 8);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int pass = 0; pass < 8; ++pass) {
+            f32x4 acc[3][2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) {
+                vec8 fb[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const vec8*>(sStage + swz64(sl * 256 + pass * 32 + j * 16 + fr, fq));
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    if (i < nfr) {
+                        const vec8 fa = *reinterpret_cast<const vec8*>(sMixed + sl * SLICE_BYTES + swz64(prow[i], fq));
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = LP<T>::mfma(fa, fb[j], acc[i][j]);
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < nfr) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sC[((wave + 8 * i) * 16 + fq * 4 + r) * CLD + j * 16 + fr] = acc[i][j][r];
+                }
+            __syncthreads();
+            for (int idx = tid; idx < NPIX * 4; idx += 512) {        // 289 pixels x 4 column groups of 8
+                const int p = idx >> 2, cg = idx & 3;
+                const int col = pass * 32 + cg * 8;
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(&sC[p * CLD + cg * 8]);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(&sC[p * CLD + cg * 8 + 4]);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b_up + col), b1 = *reinterpret_cast<const f32x4*>(a.b_up + col + 4);
+                float rv[8], v[8];
+                unpack8<T>(load_global_b128(xin, (long)p * C + col), rv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = rv[e] + a.scale * (c0[e] + b0[e]);
+                    v[4 + e] = rv[4 + e] + a.scale * (c1[e] + b1[e]);
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                *reinterpret_cast<u32x4*>(a.y + ((long)img * NPIX + p) * C + col) = pack8<T>(v);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace fn
 
 using namespace fn;
@@ -344,4 +584,34 @@ extern "C" int fn_block17_infer(const void* x, void* y, int N, const void* w_t0,
     if (dtype == FN_BF16) hipLaunchKernelGGL(block17_infer_kernel<__bf16>, dim3(N), dim3(512), smem, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(block17_infer_kernel<_Float16>, dim3(N), dim3(512), smem, (hipStream_t)stream, a);
     return check_launch("block17_infer");
+}
+
+// One Block35 of the BN-folded inference network in one launch (see the kernel).  w_1x1 / b_1x1: the three tower-entry 1x1 layers
+// (tower_conv0/Conv2d_1x1, tower_conv1/Conv2d_0a_1x1, tower_conv2/Conv2d_0a_1x1); w_3x3 / b_3x3: tower_conv1/Conv2d_0b_3x3,
+// tower_conv2/Conv2d_0b_3x3, tower_conv2/Conv2d_0c_3x3; all inference packs [Cout][taps][Cin] with the folded BN shifts.
+extern "C" int fn_block35_infer(const void* x, void* y, int N, const void* const* w_1x1, const void* const* w_3x3, const void* w_up,
+                                const float* const* b_1x1, const float* const* b_3x3, const float* b_up, float scale, int relu, int dtype,
+                                void* stream) {
+    FN_REQUIRE(dtype == FN_BF16 || dtype == FN_F16, "dtype %d unsupported", dtype);
+    FN_REQUIRE(x && y && x != y && N > 0 && w_1x1 && w_3x3 && w_up && b_1x1 && b_3x3 && b_up, "block35_infer: bad arguments");
+    Block35Args a{};
+    a.x = (const unsigned short*)x; a.y = (unsigned short*)y; a.w_up = (const unsigned short*)w_up; a.b_up = b_up;
+    for (int i = 0; i < 3; ++i) {
+        FN_REQUIRE(w_1x1[i] && w_3x3[i] && b_1x1[i] && b_3x3[i], "block35_infer: null layer %d", i);
+        a.w_1x1[i] = (const unsigned short*)w_1x1[i]; a.w_3x3[i] = (const unsigned short*)w_3x3[i];
+        a.b_1x1[i] = b_1x1[i]; a.b_3x3[i] = b_3x3[i];
+    }
+    a.scale = scale; a.relu = relu; a.N = N;
+    constexpr int SLICE = 304 * 64, PATCH = (19 * 19 * 64 + 1023) / 1024 * 1024 + 1024;
+    constexpr size_t smem = 3 * SLICE + 2 * PATCH + 2 * (SLICE + 96 * 64);
+    static_assert(smem <= 160 * 1024 && 3 * 256 * 64 <= 2 * (SLICE + 96 * 64) && 304 * 36 * 4 <= 2 * PATCH, "block35 LDS plan");
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block35_infer_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block35_infer_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (dtype == FN_BF16) hipLaunchKernelGGL(block35_infer_kernel<__bf16>, dim3(N), dim3(512), smem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(block35_infer_kernel<_Float16>, dim3(N), dim3(512), smem, (hipStream_t)stream, a);
+    return check_launch("block35_infer");
 }

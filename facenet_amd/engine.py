@@ -607,6 +607,12 @@ class Lowering:
             self.readers[trunk.buf.name] = self.readers.get(trunk.buf.name, 0) + 1
             self.recs.append(Rec("block17", None, trunk, out.full(), dict(prefix=prefix, scale=float(scale), relu=bool(relu))))
             return out.full()
+        if (not self.declare and not self.training and self.fuse_blocks and (H, W, up) == (17, 17, 256) and towers == BLOCK_TOWERS["block35"][0]
+                and trunk.c0 == 0 and trunk.C == trunk.buf.C == 256):
+            out = self.buf(prefix + "/out", H, W, up)
+            self.readers[trunk.buf.name] = self.readers.get(trunk.buf.name, 0) + 1
+            self.recs.append(Rec("block35", None, trunk, out.full(), dict(prefix=prefix, scale=float(scale), relu=bool(relu))))
+            return out.full()
         mixed = self.buf(prefix + "/mixed", H, W, cm, bn_channels=cm, need_raw=True)
         c0 = 0
         for i, t in enumerate(towers):
@@ -852,6 +858,20 @@ class Lowering:
                 d.bias = _ptr(net.P, L.bias_off)
             writes.append((tgt.act.data_ptr(), r.y.c0, r.y.c0 + r.y.C))
         self._emit(self.fwd, "conv_fwd:" + L.name, lib.fn_conv2d_fwd, C.byref(d), keep=(d,), r=reads, w=writes)
+
+    def _fwd_block35(self, r: Rec):
+        net, pre = self.net, r.extra["prefix"]
+        L1 = [net.layers[f"{pre}/{n}"] for n in ("tower_conv0/Conv2d_1x1", "tower_conv1/Conv2d_0a_1x1", "tower_conv2/Conv2d_0a_1x1")]
+        L3 = [net.layers[f"{pre}/{n}"] for n in ("tower_conv1/Conv2d_0b_3x3", "tower_conv2/Conv2d_0b_3x3", "tower_conv2/Conv2d_0c_3x3")]
+        Lu = net.layers[f"{pre}/up"]
+        arr = lambda ptrs: (C.c_void_p * 3)(*ptrs)
+        w1, w3 = arr([_ptr(net.W_infer, L.w_off) for L in L1]), arr([_ptr(net.W_infer, L.w_off) for L in L3])
+        b1, b3 = arr([_ptr(net.fold_bias, L.bn_off) for L in L1]), arr([_ptr(net.fold_bias, L.bn_off) for L in L3])
+        reads = [self._ra(r.x)] + [region(net.W_infer, L.w_off, L.w_off + L.numel) for L in L1 + L3 + [Lu]] + \
+                [region(net.fold_bias, L.bn_off, L.bn_off + L.cout) for L in L1 + L3] + [region(net.P, Lu.bias_off, Lu.bias_off + Lu.cout)]
+        self._emit(self.fwd, "block35_fused:" + pre, net.lib.fn_block35_infer, _ptr(r.x.buf.act), _ptr(r.y.buf.act), self.N, w1, w3,
+                   _ptr(net.W_infer, Lu.w_off), b1, b3, _ptr(net.P, Lu.bias_off), r.extra["scale"], 1 if r.extra["relu"] else 0, self.dt,
+                   keep=(w1, w3, b1, b3), r=reads, w=[self._ra(r.y)])
 
     def _fwd_block17(self, r: Rec):
         net, pre = self.net, r.extra["prefix"]

@@ -117,6 +117,12 @@ typedef struct fn_conv_desc {
 int fn_block17_infer(const void* x, void* y, int N, const void* w_t0, const void* w_t1a, const void* w_t1b, const void* w_t1c, const void* w_up,
                      const float* b_t0, const float* b_t1a, const float* b_t1b, const float* b_t1c, const float* b_up, float scale, int relu,
                      int dtype, void* stream);
+/* One Inception-ResNet-A block ("Block35", inception_resnet_v1.py:83-150) of the BN-folded inference network in ONE launch (seven
+ * convolution launches otherwise): x, y [N,17,17,256]; w_1x1 / b_1x1: the three tower-entry 1x1 layers (tower_conv0/Conv2d_1x1,
+ * tower_conv1/Conv2d_0a_1x1, tower_conv2/Conv2d_0a_1x1); w_3x3 / b_3x3: tower_conv1/Conv2d_0b_3x3, tower_conv2/Conv2d_0b_3x3,
+ * tower_conv2/Conv2d_0c_3x3; w_up / b_up: the `up` layer [256][96] and its bias.  Arrays of 3 device pointers (host arrays). */
+int fn_block35_infer(const void* x, void* y, int N, const void* const* w_1x1, const void* const* w_3x3, const void* w_up,
+                     const float* const* b_1x1, const float* const* b_3x3, const float* b_up, float scale, int relu, int dtype, void* stream);
 int fn_conv2d_fwd(const fn_conv_desc* d, void* stream);
 int fn_conv2d_dgrad(const fn_conv_desc* d, void* stream);
 int fn_conv2d_wgrad(const fn_conv_desc* d, void* stream);
