@@ -75,9 +75,34 @@ __device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((c
         }                                                                                   \
     }
 
-template <typename T>
+// LDS-DMA form of the weight stream of stages 2-4 (template DMA): the slabs go global -> LDS directly (buffer_load ... lds, 1 KiB per
+// wave instruction, the chunk XOR of the LDS layout applied to the per-lane SOURCE address), three LDS buffers, a counted
+// s_waitcnt vmcnt(2) + a raw s_barrier per k tile -- no staging registers, no ds_write, the next two tiles stay in flight across
+// the barrier (cdna_hip_programming.md section 5, "Pipelining across barriers").  NB buffers: tile kt lives in buffer kt % 3.
+#define FN_DMA_PIPELINE(U_, NT_, ISSUE, COMPUTE)                                          \
+    {                                                                                       \
+        ISSUE(0, 0)                                                                         \
+        ISSUE(min(1, (NT_) - 1), 1)                                                         \
+        for (int kt0_ = 0; kt0_ < (NT_); kt0_ += (U_)) {                                    \
+            _Pragma("unroll") for (int d_ = 0; d_ < (U_); ++d_) {                           \
+                const int kt_ = kt0_ + d_;                                                  \
+                if (kt_ < (NT_)) {                                                          \
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   /* this wave's share of tile kt has landed */ \
+                    __builtin_amdgcn_s_barrier();                      /* everybody's has; buffer (kt + 2) % 3 is free */ \
+                    ISSUE(min(kt_ + 2, (NT_) - 1), (d_ + 2) % 3)                            \
+                    COMPUTE(kt_, d_ % 3, d_)                                                \
+                }                                                                           \
+            }                                                                               \
+        }                                                                                   \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
+        __builtin_amdgcn_s_barrier();                                                       \
+    }
+
+template <typename T, bool DMA>
 __global__ __launch_bounds__(512) void block17_infer_kernel(const Block17Args a) {
     constexpr int C = 896, CT = 128, NPIX = 64, D = 4;
+    constexpr int DMA_BUF = 16 * 1024;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
     constexpr int PATCH_PIX = 112;                        // 8 x 14 (t1a) or 14 x 8 (t1b)
     constexpr int MIXED_BYTES = 8 * NPIX * 64;            // 8 slices: t0 (4) | t1c (4)
     constexpr int PATCH_BYTES = 4 * PATCH_PIX * 64;       // 4 slices
@@ -233,7 +258,43 @@ __global__ __launch_bounds__(512) void block17_infer_kernel(const Block17Args a)
                 if (g == 0) { S23_TAP(1, buf, (d) & 1) } else if (g == 1) { S23_TAP(3, buf, (d) & 1) } else { S23_TAP(5, buf, (d) & 1) } \
             }                                                                                                                    \
         }
-        FN_RING_PIPELINE(D, 14, S23_LOAD, SLAB_STORE, S23_COMPUTE)
+        if constexpr (DMA) {
+            // unrolled by 6 from multiples of 6: buffer = d % 3, half = d & 1, tap = 3 (kt0 / 6) + (d >> 1)
+#define S23_DMA_ISSUE(kt, buf)                                                                                               \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                        \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(sStage + (buf) * DMA_BUF + (wave * 16 + 8 * q) * 128), 16,   \
+                                                         dma_voff23[q], (((kt) >> 1) * CT + ((kt) & 1) * 64) * 2, 0, 0);
+#define S23_DMA_FB(buf, h, j) *reinterpret_cast<const vec8*>(sStage + (buf) * DMA_BUF + fb_off[h][j])
+#define S23_DMA_TAP(TAP, buf, half)                                                                                              \
+            _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                                      \
+                vec8 fa[2], fb[2];                                                                                               \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                    \
+                    fa[i] = *reinterpret_cast<const vec8*>(src + ((half) * 2 + h) * (PATCH_PIX * 64) + fa_off[TAP][i]);          \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) fb[j] = S23_DMA_FB(buf, h, j);                                     \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                    \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = LP<T>::mfma(fa[i], fb[j], acc[i][j]);              \
+            }
+#define S23_DMA_COMPUTE(kt, buf, d)                                                                                              \
+            {                                                                                                                    \
+                const int g = (kt) / 6;                /* uniform */                                                             \
+                if (((d) >> 1) == 0) { if (g == 0) { S23_DMA_TAP(0, buf, (d) & 1) } else if (g == 1) { S23_DMA_TAP(3, buf, (d) & 1) } else { S23_DMA_TAP(6, buf, (d) & 1) } } \
+                else if (((d) >> 1) == 1) { if (g == 0) { S23_DMA_TAP(1, buf, (d) & 1) } else { S23_DMA_TAP(4, buf, (d) & 1) } } \
+                else { if (g == 0) { S23_DMA_TAP(2, buf, (d) & 1) } else { S23_DMA_TAP(5, buf, (d) & 1) } }                      \
+            }
+            int dma_voff23[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = wave * 16 + 8 * q + (lane >> 3), cs = (lane & 7) ^ (r & 7);
+                dma_voff23[q] = (r * (7 * CT) + cs * 8) * 2;
+            }
+            FN_DMA_PIPELINE(6, 14, S23_DMA_ISSUE, S23_DMA_COMPUTE)
+#undef S23_DMA_ISSUE
+#undef S23_DMA_FB
+#undef S23_DMA_TAP
+#undef S23_DMA_COMPUTE
+        } else {
+            FN_RING_PIPELINE(D, 14, S23_LOAD, SLAB_STORE, S23_COMPUTE)
+        }
 #undef S23_LOAD
 #undef S23_TAP
 #undef S23_COMPUTE
@@ -312,7 +373,65 @@ __global__ __launch_bounds__(512) void block17_infer_kernel(const Block17Args a)
                 }                                                                                                                \
             }                                                                                                                    \
         }
-        FN_RING_PIPELINE(D, 28, S4_LOAD, SLAB_STORE, S4_COMPUTE)
+        if constexpr (DMA) {
+            // unrolled by 12 from multiples of 12: buffer = d % 3, kk = d & 3
+            int dma_voff4[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = wave * 16 + 8 * q + (lane >> 3), cs = (lane & 7) ^ (r & 7);
+                dma_voff4[q] = (r * 256 + cs * 8) * 2;
+            }
+#define S4_DMA_ISSUE(kt, buf)                                                                                                    \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                        \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(sStage + (buf) * DMA_BUF + (wave * 16 + 8 * q) * 128), 16,   \
+                                                         dma_voff4[q], ((((kt) >> 2) * 128) * 256 + ((kt) & 3) * 64) * 2, 0, 0);
+#define S4_DMA_COMPUTE(kt, buf, d)                                                                                               \
+            {                                                                                                                    \
+                if (((d) & 3) == 0) {                                                                                            \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
+                        _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};                     \
+                }                                                                                                                \
+                _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                                  \
+                    vec8 fa[2], fb[2];                                                                                           \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
+                        fa[i] = *reinterpret_cast<const vec8*>(sMixed + (((d) & 3) * 2 + h) * (NPIX * 64) + fa_off[i]);          \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const vec8*>(sStage + (buf) * DMA_BUF + fb_off[h][j]); \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
+                        _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = LP<T>::mfma(fa[i], fb[j], acc[i][j]);          \
+                }                                                                                                                \
+                if (((d) & 3) == 3) {                                                                                            \
+                    const int pass = (kt) >> 2;                                                                                  \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
+                        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+                            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                        \
+                                sC[(wh * 32 + i * 16 + fq * 4 + r) * CLD + wq * 32 + j * 16 + fr] = acc[i][j][r];                \
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+                    __builtin_amdgcn_s_barrier();                                                                                \
+                    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                              \
+                        const int idx = tid + 512 * q, p = idx >> 4, cg = idx & 15;                                              \
+                        const int col = pass * 128 + cg * 8;                                                                     \
+                        const f32x4 c0 = *reinterpret_cast<const f32x4*>(&sC[p * CLD + cg * 8]);                                 \
+                        const f32x4 c1 = *reinterpret_cast<const f32x4*>(&sC[p * CLD + cg * 8 + 4]);                             \
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b_up + col), b1 = *reinterpret_cast<const f32x4*>(a.b_up + col + 4); \
+                        float rv[8], v[8];                                                                                       \
+                        unpack8<T>(load_global_b128(xin, (long)p * C + col), rv);                                                \
+                        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                          \
+                            v[e] = rv[e] + a.scale * (c0[e] + b0[e]);                                                            \
+                            v[4 + e] = rv[4 + e] + a.scale * (c1[e] + b1[e]);                                                    \
+                        }                                                                                                        \
+                        if (a.relu) {                                                                                            \
+                            _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);                               \
+                        }                                                                                                        \
+                        *reinterpret_cast<u32x4*>(a.y + ((long)img * NPIX + p) * C + col) = pack8<T>(v);                         \
+                    }                                                                                                            \
+                }                                                                                                                \
+            }
+            FN_DMA_PIPELINE(12, 28, S4_DMA_ISSUE, S4_DMA_COMPUTE)
+#undef S4_DMA_ISSUE
+#undef S4_DMA_COMPUTE
+        } else {
+            FN_RING_PIPELINE(D, 28, S4_LOAD, SLAB_STORE, S4_COMPUTE)
+        }
 #undef S4_LOAD
 #undef S4_COMPUTE
     }
@@ -574,15 +693,23 @@ extern "C" int fn_block17_infer(const void* x, void* y, int N, const void* w_t0,
     Block17Args a{(const unsigned short*)x, (unsigned short*)y, (const unsigned short*)w_t0, (const unsigned short*)w_t1a,
                   (const unsigned short*)w_t1b, (const unsigned short*)w_t1c, (const unsigned short*)w_up, b_t0, b_t1a, b_t1b, b_t1c, b_up,
                   scale, relu, N, getenv("FN_B17_STOP") ? atoi(getenv("FN_B17_STOP")) : 0};
-    constexpr size_t smem = 8 * 64 * 64 + 2 * 4 * 112 * 64 + 2 * 20 * 1024;
+    constexpr size_t smem = 8 * 64 * 64 + 2 * 4 * 112 * 64 + 3 * 16 * 1024;      // staging: 2 x 20 KB (register ring) or 3 x 16 KB (LDS-DMA)
+    static const int use_dma = getenv("FN_B17_DMA") ? atoi(getenv("FN_B17_DMA")) : 1;   // measured: stages 2+3 12.4 -> 9.6 us per block (tools/dev_block17.py)
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block17_infer_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block17_infer_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block17_infer_kernel<__bf16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block17_infer_kernel<_Float16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block17_infer_kernel<__bf16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block17_infer_kernel<_Float16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (dtype == FN_BF16) hipLaunchKernelGGL(block17_infer_kernel<__bf16>, dim3(N), dim3(512), smem, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(block17_infer_kernel<_Float16>, dim3(N), dim3(512), smem, (hipStream_t)stream, a);
+    if (use_dma) {
+        if (dtype == FN_BF16) hipLaunchKernelGGL((block17_infer_kernel<__bf16, true>), dim3(N), dim3(512), smem, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((block17_infer_kernel<_Float16, true>), dim3(N), dim3(512), smem, (hipStream_t)stream, a);
+    } else {
+        if (dtype == FN_BF16) hipLaunchKernelGGL((block17_infer_kernel<__bf16, false>), dim3(N), dim3(512), smem, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((block17_infer_kernel<_Float16, false>), dim3(N), dim3(512), smem, (hipStream_t)stream, a);
+    }
     return check_launch("block17_infer");
 }
 
