@@ -48,8 +48,11 @@ def main():
     note = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no trace flags) over: python bench.py --steps 4 --warmup 2 "
             "--no-cpu-baseline; counters in KiB per dispatch; FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B, "
             "MI355X_MICROARCH.md HBM section); per-launch averages over every dispatch of the kernel in the run")
+    sig = None
+    if len(sys.argv) > 4:          # the bench line of the same tile cache: its tile_signature ties `roofline.traffic` to these passes
+        sig = json.load(open(sys.argv[4])).get("tile_signature")
     with open(out, "w") as fh:
-        json.dump({"note": note, "kernels": kernels}, fh, indent=1)
+        json.dump({"note": note, "tile_signature": sig, "kernels": kernels}, fh, indent=1)
     print(f"{len(kernels)} kernels -> {out}")
 
 
