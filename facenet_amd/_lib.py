@@ -37,7 +37,7 @@ class ConvDesc(C.Structure):
         ("dy2", C.c_void_p), ("w2", C.c_void_p), ("dy3", C.c_void_p), ("w3", C.c_void_p),
         ("Cout2", C.c_int32), ("ld_y2", C.c_int32), ("Cout3", C.c_int32), ("ld_y3", C.c_int32),
         ("rb_prev", C.c_void_p), ("rb_out", C.c_void_p), ("rb_dtrunk", C.c_void_p), ("rb_dup", C.c_void_p), ("rb_dbias", C.c_void_p),
-        ("rb_scale", C.c_float), ("rb_accumulate", C.c_int32),
+        ("rb_scale", C.c_float), ("rb_accumulate", C.c_int32), ("prelu", C.c_void_p),
     ]
 
 
@@ -71,6 +71,10 @@ _SIGNATURES = {
     "fn_bn_relu_train_bwd": [_p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "fn_maxpool3x3s2_fwd": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p],
     "fn_maxpool3x3s2_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p],
+    "fn_area_resize_crop": [_p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p],
+    "fn_maxpool2d_fwd": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "fn_mtcnn_candidates": [_p, C.c_long, _i, _f, _p, _p, _i, _p],
+    "fn_nms_greedy": [_p, _i, _p, _i, C.c_double, _i, _p, C.c_long, _p, _p, _p],
     "fn_avgpool_fwd": [_p, _p, _i, _i, _i, _i, _p],
     "fn_avgpool_bwd": [_p, _p, _i, _i, _i, _i, _p],
     "fn_residual_bwd": [_p, _p, _p, _p, _p, _i, _i, _f, _i, _i, _i, _p],

@@ -78,6 +78,7 @@ struct ConvArgs {
     unsigned short* out2;         // scale2 * (masked gradient), geometry of out
     float* colsum;                // += column sums of what goes to out2
     float scale2;
+    const float* prelu;           // forward: per-output-channel PReLU slope applied to conv + bias
 };
 
 // q = m / d, r = m % d through the hardware reciprocal (0 <= m < 2^24, d > 0): integer division is a ~40-instruction
@@ -168,6 +169,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
         float bias[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) bias[e] = (a.bias && col + e < a.NOUT) ? a.bias[col + e] : 0.f;
+        float slope[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) slope[e] = (a.prelu && col + e < a.NOUT) ? a.prelu[col + e] : 1.f;
         const bool full = (col + 8 <= a.NOUT);
 #pragma unroll
         for (int ps = 0; ps < (BM + RP - 1) / RP; ++ps) {
@@ -187,6 +191,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
             for (int e = 0; e < 4; ++e) {
                 v[e] = c0[e] + bias[e];
                 v[4 + e] = c1[e] + bias[4 + e];
+            }
+            if (a.prelu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : slope[e] * v[e];
             }
             if (a.resid) {
                 float rv[8];
@@ -1374,6 +1382,8 @@ static int make_fwd_args(const fn_conv_desc* d, ConvArgs& a) {
     a = ConvArgs{};
     a.src = (const unsigned short*)d->x; a.wp = (const unsigned short*)d->w; a.out = d->y;
     a.bias = d->bias; a.stats = d->stats; a.resid = (const unsigned short*)d->resid;
+    FN_REQUIRE(!d->prelu || (!d->resid && !d->relu && !d->accumulate && !d->stats), "conv_fwd: prelu excludes resid / relu / accumulate / stats");
+    a.prelu = d->prelu;
     a.M = d->N * d->OH * d->OW; a.PH = d->OH; a.PW = d->OW; a.SH = d->H; a.SW = d->W; a.CS = d->Cin;
     a.NOUT = d->Cout; a.KTOT = d->KH * d->KW * d->Cin; a.KH = d->KH; a.KW = d->KW;
     a.so = d->stride; a.sk = 1; a.offy = -d->pad_h; a.offx = -d->pad_w; a.dshift = 0;

@@ -1,0 +1,337 @@
+// Device side of the MTCNN face detector behind the reference's detectors/face_detector.py:63-78 (a wrapper around the PyPI
+// `mtcnn` package, whose arithmetic is restated in oracle/mtcnn_oracle.py): everything of the cascade that touches pixels or
+// feature maps and is not a convolution.  The convolutions / dense layers themselves are fn_conv2d_fwd launches with the PReLU
+// epilogue (fn_conv_desc.prelu).
+//   * fn_area_resize_crop   zero-padded crop of the uint8 frame -> cv2.resize(..., INTER_AREA) -> (x - 127.5) / 128 ->
+//                           transposed [x][y] low-precision NHWC with 8 channels (3 + zero padding): the image pyramid of
+//                           stage 1 (one "crop" = the whole frame) and the 24x24 / 48x48 candidate crops of stages 2 and 3
+//   * fn_maxpool2d_fwd      MaxPooling2D(k, strides=s, 'valid' | 'same') with windows clipped at the map border
+//   * fn_mtcnn_candidates   softmax over the two class logits of the P-Net map, threshold, compaction of (cell, score, reg)
+// HBM-bound byte / elementwise work: coalesced 16-byte accesses, no LDS needed.
+#include "../../include/facenet_hip.h"
+#include "common.h"
+
+namespace fn {
+
+// One entry list of cv2's computeResizeAreaTab for ONE destination index d (imgproc/resize.cpp): source cells [s_first, ..]
+// with weights: an optional leading partial cell, full cells, an optional trailing partial cell.
+struct AreaSpan {
+    int lead;       // source index of the leading partial cell or -1
+    float a_lead;
+    int s1, s2;     // full cells s1 .. s2-1
+    float a_full;
+    int trail;      // source index of the trailing partial cell or -1
+    float a_trail;
+};
+
+__device__ __forceinline__ AreaSpan area_span(int d, int ssize, double scale) {
+#pragma clang fp contract(off)
+    AreaSpan t;
+    const double fsx1 = d * scale;
+    const double fsx2 = fsx1 + scale;
+    const double cell = fmin(scale, (double)ssize - fsx1);
+    int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+    sx2 = min(sx2, ssize - 1);
+    sx1 = min(sx1, sx2);
+    t.lead = -1; t.trail = -1; t.a_lead = 0.f; t.a_trail = 0.f;
+    if (sx1 - fsx1 > 1e-3) { t.lead = sx1 - 1; t.a_lead = (float)((sx1 - fsx1) / cell); }
+    t.s1 = sx1; t.s2 = sx2;
+    t.a_full = (float)(1.0 / cell);
+    if (fsx2 - sx2 > 1e-3) { t.trail = sx2; t.a_trail = (float)(fmin(fmin(fsx2 - sx2, 1.0), cell) / cell); }
+    return t;
+}
+
+// cv2's "area mode" bilinear coordinates (used by INTER_AREA whenever one axis is enlarged)
+// horizontal: the last source column takes weight 1 (fx = 0); vertical: the row pair is only clipped (resizeGeneric_Invoker)
+__device__ __forceinline__ void area_linear_coord(int d, int ssize, double scale, double inv_scale, bool horizontal, int& s, float& f) {
+#pragma clang fp contract(off)
+    s = (int)floor(d * scale);
+    f = (float)((d + 1) - (s + 1) * inv_scale);
+    f = f <= 0.f ? 0.f : f - floorf(f);
+    if (horizontal) {
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    } else {
+        s = min(max(s, 0), ssize - 1);
+    }
+}
+
+template <typename WT> struct Px3 { WT c[3]; };
+
+template <typename WT>
+__device__ __forceinline__ Px3<WT> frame_px(const uint8_t* __restrict__ frame, int H, int W, int y, int x) {
+    Px3<WT> p;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+        const uint8_t* s = frame + ((long)y * W + x) * 3;
+        p.c[0] = (WT)s[0]; p.c[1] = (WT)s[1]; p.c[2] = (WT)s[2];
+    } else {
+        p.c[0] = p.c[1] = p.c[2] = (WT)0;
+    }
+    return p;
+}
+
+// boxes[k] = (ox, oy, cw, ch): crop of cw x ch pixels whose pixel (0,0) is frame pixel (ox, oy); outside the frame = 0.
+// WT = float + round_u8 for a uint8 source (cv2 on uint8: float accumulators, saturate_cast<uchar> = round half to even);
+// WT = double for the float64 crops of stages 2 / 3 (no rounding).
+template <typename T, typename WT>
+__global__ __launch_bounds__(256) void area_resize_crop_kernel(const uint8_t* __restrict__ frame, int H, int W, const int32_t* __restrict__ boxes,
+                                                               int n, int OH, int OW, int round_u8, unsigned short* __restrict__ out) {
+#pragma clang fp contract(off)
+    const long total = (long)n * OH * OW;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        // consecutive threads -> consecutive dy of one dx: the transposed store is coalesced
+        const int dy = (int)(t % OH);
+        const int dx = (int)((t / OH) % OW);
+        const int k = (int)(t / ((long)OH * OW));
+        const int ox = boxes[4 * k], oy = boxes[4 * k + 1], cw = boxes[4 * k + 2], ch = boxes[4 * k + 3];
+        WT r[3] = {(WT)0, (WT)0, (WT)0};
+        if (cw > 0 && ch > 0) {
+            const double inv_sx = (double)OW / cw, inv_sy = (double)OH / ch;
+            const double scale_x = 1.0 / inv_sx, scale_y = 1.0 / inv_sy;
+            if (scale_x >= 1.0 && scale_y >= 1.0) {   // true area resampling
+                const AreaSpan xs = area_span(dx, cw, scale_x), ys = area_span(dy, ch, scale_y);
+                bool first = true;
+                const int ny = (ys.lead >= 0) + (ys.s2 - ys.s1) + (ys.trail >= 0);
+                for (int j = 0; j < ny; ++j) {
+                    int sy; float beta;
+                    if (ys.lead >= 0 && j == 0) { sy = ys.lead; beta = ys.a_lead; }
+                    else {
+                        const int jj = j - (ys.lead >= 0);
+                        if (jj < ys.s2 - ys.s1) { sy = ys.s1 + jj; beta = ys.a_full; }
+                        else { sy = ys.trail; beta = ys.a_trail; }
+                    }
+                    WT buf[3] = {(WT)0, (WT)0, (WT)0};
+                    if (xs.lead >= 0) {
+                        const Px3<WT> p = frame_px<WT>(frame, H, W, oy + sy, ox + xs.lead);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) buf[c] = buf[c] + p.c[c] * (WT)xs.a_lead;
+                    }
+                    for (int sx = xs.s1; sx < xs.s2; ++sx) {
+                        const Px3<WT> p = frame_px<WT>(frame, H, W, oy + sy, ox + sx);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) buf[c] = buf[c] + p.c[c] * (WT)xs.a_full;
+                    }
+                    if (xs.trail >= 0) {
+                        const Px3<WT> p = frame_px<WT>(frame, H, W, oy + sy, ox + xs.trail);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) buf[c] = buf[c] + p.c[c] * (WT)xs.a_trail;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) r[c] = first ? (WT)beta * buf[c] : r[c] + (WT)beta * buf[c];
+                    first = false;
+                }
+            } else {   // one axis enlarged: bilinear with the area-mode coordinates
+                int sx, sy; float fx, fy;
+                area_linear_coord(dx, cw, scale_x, inv_sx, true, sx, fx);
+                area_linear_coord(dy, ch, scale_y, inv_sy, false, sy, fy);
+                const int sx1 = min(sx + 1, cw - 1), sy1 = min(sy + 1, ch - 1);
+                const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+                const Px3<WT> p00 = frame_px<WT>(frame, H, W, oy + sy, ox + sx), p01 = frame_px<WT>(frame, H, W, oy + sy, ox + sx1);
+                const Px3<WT> p10 = frame_px<WT>(frame, H, W, oy + sy1, ox + sx), p11 = frame_px<WT>(frame, H, W, oy + sy1, ox + sx1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const WT h0 = p00.c[c] * (WT)a0 + p01.c[c] * (WT)a1;
+                    const WT h1 = p10.c[c] * (WT)a0 + p11.c[c] * (WT)a1;
+                    r[c] = h0 * (WT)b0 + h1 * (WT)b1;
+                }
+            }
+        }
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            WT q = r[c];
+            if (round_u8) q = (WT)fminf(fmaxf(rintf((float)q), 0.f), 255.f);
+            v[c] = (float)((q - (WT)127.5) * (WT)0.0078125);
+        }
+#pragma unroll
+        for (int c = 3; c < 8; ++c) v[c] = 0.f;
+        *reinterpret_cast<u32x4*>(out + (((long)k * OW + dx) * OH + dy) * 8) = pack8<T>(v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2d_fwd_kernel(const unsigned short* __restrict__ x, int ld_x, unsigned short* __restrict__ y, int ld_y,
+                                                            int N, int H, int W, int C, int k, int stride, int pad_h, int pad_w, int OH, int OW) {
+    const int CG = C >> 3;
+    const long total = (long)N * OH * OW * CG;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int cg = (int)(t % CG);
+        long pix = t / CG;
+        const int ox = (int)(pix % OW); pix /= OW;
+        const int oy = (int)(pix % OH);
+        const int n = (int)(pix / OH);
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -3.0e38f;
+        const int y0 = max(oy * stride - pad_h, 0), y1 = min(oy * stride - pad_h + k, H);
+        const int x0 = max(ox * stride - pad_w, 0), x1 = min(ox * stride - pad_w + k, W);
+        for (int iy = y0; iy < y1; ++iy)
+            for (int ix = x0; ix < x1; ++ix) {
+                float v[8];
+                unpack8<T>(*reinterpret_cast<const u32x4*>(x + ((long)(n * H + iy) * W + ix) * ld_x + cg * 8), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+        *reinterpret_cast<u32x4*>(y + ((long)(n * OH + oy) * OW + ox) * ld_y + cg * 8) = pack8<T>(m);
+    }
+}
+
+// P-Net output map, one row of `ld` floats per cell: [logit0, logit1, reg0..reg3, ...].  Keras Softmax(axis=3) in fp32:
+// e = exp(l - max(l)); p1 = e1 / (e0 + e1).  Cells with p1 >= threshold are appended (any order) as
+// (cell index, p1, reg0..reg3); *counter counts every hit, also those beyond max_cand (the host then reruns with more room).
+__global__ __launch_bounds__(256) void mtcnn_candidates_kernel(const float* __restrict__ map, long ncell, int ld, float threshold,
+                                                               float* __restrict__ cand, int* __restrict__ counter, int max_cand) {
+#pragma clang fp contract(off)
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < ncell; t += (long)gridDim.x * 256) {
+        const float* r = map + t * ld;
+        const float2 l = *reinterpret_cast<const float2*>(r);
+        const float mx = fmaxf(l.x, l.y);
+        const float e0 = expf(l.x - mx), e1 = expf(l.y - mx);
+        const float p1 = e1 / (e0 + e1);
+        if (p1 >= threshold) {
+            const int slot = atomicAdd(counter, 1);
+            if (slot < max_cand) {
+                float* o = cand + (long)slot * 6;
+                o[0] = __int_as_float((int)t);
+                o[1] = p1;
+                o[2] = r[2]; o[3] = r[3]; o[4] = r[4]; o[5] = r[5];
+            }
+        }
+    }
+}
+
+
+// ---- greedy non-maximum suppression (the package's __nms) ----------------------------------------------------------------
+// Candidates are visited in rank order (rank r = box order[n-1-r]: the host's np.argsort of the scores, best first); a visited
+// box that is still alive is kept and removes every later box whose overlap ratio o fails `o <= threshold`.  The O(n^2) part --
+// all pairwise ratios, in float64 with the package's operation order (no contraction) -- is one bit matrix; the inherently
+// serial part is a scan that resolves 64 ranks at a time inside one wave and ORs the kept rows into the `removed` bit set.
+__global__ __launch_bounds__(64) void nms_mask_kernel(const double* __restrict__ boxes, int ld, const int32_t* __restrict__ order, int n,
+                                                      double threshold, int by_min, unsigned long long* __restrict__ mask, int W) {
+#pragma clang fp contract(off)
+    const int rb = blockIdx.y, cb = blockIdx.x, t = threadIdx.x;
+    if (cb < rb) return;
+    __shared__ double sx1[64], sy1[64], sx2[64], sy2[64], sar[64];
+    const int cj = cb * 64 + t;
+    if (cj < n) {
+        const double* b = boxes + (long)order[n - 1 - cj] * ld;
+        sx1[t] = b[0]; sy1[t] = b[1]; sx2[t] = b[2]; sy2[t] = b[3];
+        sar[t] = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+    }
+    __syncthreads();
+    const int i = rb * 64 + t;
+    if (i >= n) return;
+    const double* b = boxes + (long)order[n - 1 - i] * ld;
+    const double x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
+    const double area = (x2 - x1 + 1) * (y2 - y1 + 1);
+    unsigned long long bits = 0;
+    const int jn = min(64, n - cb * 64);
+    for (int j = 0; j < jn; ++j) {
+        if (cb * 64 + j <= i) continue;
+        const double w = fmax(0.0, fmin(x2, sx2[j]) - fmax(x1, sx1[j]) + 1);
+        const double h = fmax(0.0, fmin(y2, sy2[j]) - fmax(y1, sy1[j]) + 1);
+        const double inter = w * h;
+        const double o = by_min ? inter / fmin(area, sar[j]) : inter / (area + sar[j] - inter);
+        if (!(o <= threshold)) bits |= 1ull << j;
+    }
+    mask[(long)i * W + cb] = bits;
+}
+
+__global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int W, const int32_t* __restrict__ order,
+                                                       int32_t* __restrict__ keep, int32_t* __restrict__ n_keep) {
+    extern __shared__ unsigned long long removed[];
+    __shared__ unsigned long long s_kept;
+    const int tid = threadIdx.x;
+    for (int w = tid; w < W; w += 256) removed[w] = 0;
+    int count = 0;   // meaningful in wave 0
+    __syncthreads();
+    for (int b = 0; b < W; ++b) {
+        if (tid < 64) {
+            const int row = b * 64 + tid;
+            const unsigned long long diag = row < n ? mask[(long)row * W + b] : 0ull;
+            unsigned long long rem = removed[b];
+            if (n - b * 64 < 64) rem |= ~0ull << (n - b * 64);       // ranks beyond n do not exist
+            unsigned long long kept = 0;
+            for (int t = 0; t < 64; ++t) {
+                const unsigned long long d = __shfl(diag, t);
+                if (!((rem >> t) & 1ull)) { kept |= 1ull << t; rem |= d; }
+            }
+            if ((kept >> tid) & 1ull) keep[count + __popcll(kept & ((1ull << tid) - 1ull))] = order[n - 1 - row];
+            count += __popcll(kept);
+            if (tid == 0) s_kept = kept;
+        }
+        __syncthreads();
+        const unsigned long long kept = s_kept;
+        for (int w = b + 1 + tid; w < W; w += 256) {
+            unsigned long long acc = 0, k = kept;
+            while (k) {
+                const int t = __ffsll((long long)k) - 1;
+                k &= k - 1;
+                acc |= mask[(long)(b * 64 + t) * W + w];
+            }
+            removed[w] |= acc;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *n_keep = count;
+}
+
+static inline int grid_of(long items, int cap = 8192) {
+    long b = (items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace fn
+
+using namespace fn;
+
+extern "C" int fn_area_resize_crop(const uint8_t* frame, int H, int W, const int32_t* boxes, int n, int OH, int OW, int source_is_u8, void* out,
+                                   int dtype, void* stream) {
+    FN_REQUIRE(frame && boxes && out && H > 0 && W > 0 && n > 0 && OH > 0 && OW > 0, "area_resize_crop: bad arguments");
+    FN_REQUIRE(dtype == DT_BF16 || dtype == DT_F16, "area_resize_crop: dtype %d", dtype);
+    const int grid = grid_of((long)n * OH * OW);
+    hipStream_t st = (hipStream_t)stream;
+    if (source_is_u8) {
+        if (dtype == DT_F16) hipLaunchKernelGGL((area_resize_crop_kernel<_Float16, float>), dim3(grid), dim3(256), 0, st, frame, H, W, boxes, n, OH, OW, 1, (unsigned short*)out);
+        else hipLaunchKernelGGL((area_resize_crop_kernel<__bf16, float>), dim3(grid), dim3(256), 0, st, frame, H, W, boxes, n, OH, OW, 1, (unsigned short*)out);
+    } else {
+        if (dtype == DT_F16) hipLaunchKernelGGL((area_resize_crop_kernel<_Float16, double>), dim3(grid), dim3(256), 0, st, frame, H, W, boxes, n, OH, OW, 0, (unsigned short*)out);
+        else hipLaunchKernelGGL((area_resize_crop_kernel<__bf16, double>), dim3(grid), dim3(256), 0, st, frame, H, W, boxes, n, OH, OW, 0, (unsigned short*)out);
+    }
+    return check_launch("area_resize_crop");
+}
+
+extern "C" int fn_maxpool2d_fwd(const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, int k, int stride, int pad_h, int pad_w,
+                                int OH, int OW, int dtype, void* stream) {
+    FN_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && ld_x % 8 == 0 && ld_y % 8 == 0 && ld_x >= C && ld_y >= C,
+               "maxpool2d: bad arguments");
+    FN_REQUIRE(k >= 1 && stride >= 1 && pad_h >= 0 && pad_w >= 0 && pad_h < k && pad_w < k && OH > 0 && OW > 0, "maxpool2d: bad window");
+    // every window must hold at least one real element
+    FN_REQUIRE((OH - 1) * stride - pad_h < H && (OW - 1) * stride - pad_w < W, "maxpool2d: output %dx%d exceeds the input %dx%d", OH, OW, H, W);
+    FN_REQUIRE(dtype == DT_BF16 || dtype == DT_F16, "maxpool2d: dtype %d", dtype);
+    const int grid = grid_of((long)N * OH * OW * (C / 8));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DT_F16) hipLaunchKernelGGL((maxpool2d_fwd_kernel<_Float16>), dim3(grid), dim3(256), 0, st, (const unsigned short*)x, ld_x, (unsigned short*)y, ld_y, N, H, W, C, k, stride, pad_h, pad_w, OH, OW);
+    else hipLaunchKernelGGL((maxpool2d_fwd_kernel<__bf16>), dim3(grid), dim3(256), 0, st, (const unsigned short*)x, ld_x, (unsigned short*)y, ld_y, N, H, W, C, k, stride, pad_h, pad_w, OH, OW);
+    return check_launch("maxpool2d");
+}
+
+extern "C" int fn_mtcnn_candidates(const float* map, long ncell, int ld, float threshold, float* cand, int32_t* counter, int max_cand, void* stream) {
+    FN_REQUIRE(map && cand && counter && ncell > 0 && ld >= 6 && ld % 2 == 0 && max_cand > 0, "mtcnn_candidates: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    fill_words((unsigned*)counter, 0u, 0u, 1, st);
+    hipLaunchKernelGGL(mtcnn_candidates_kernel, dim3(grid_of(ncell)), dim3(256), 0, st, map, ncell, ld, threshold, cand, (int*)counter, max_cand);
+    return check_launch("mtcnn_candidates");
+}
+
+extern "C" int fn_nms_greedy(const double* boxes, int ld, const int32_t* order, int n, double threshold, int by_min, void* workspace,
+                             long workspace_bytes, int32_t* keep, int32_t* n_keep, void* stream) {
+    FN_REQUIRE(boxes && order && workspace && keep && n_keep && n > 0 && ld >= 4, "nms_greedy: bad arguments");
+    const int W = (n + 63) / 64;
+    FN_REQUIRE((long)n * W * 8 <= workspace_bytes, "nms_greedy: workspace of %ld bytes is too small for n=%d (%ld needed)", workspace_bytes, n, (long)n * W * 8);
+    FN_REQUIRE(W * 8 <= 64 * 1024, "nms_greedy: n=%d exceeds the scan's bit set (524288 boxes)", n);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(W, W), dim3(64), 0, st, boxes, ld, order, n, threshold, by_min, (unsigned long long*)workspace, W);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(256), (size_t)W * 8, st, (const unsigned long long*)workspace, n, W, order, keep, n_keep);
+    return check_launch("nms_greedy");
+}

@@ -107,6 +107,10 @@ typedef struct fn_conv_desc {
     float* rb_dbias;
     float rb_scale;
     int32_t rb_accumulate;
+    /* fwd, optional: PReLU with one slope per output channel (Keras PReLU(shared_axes=[1,2]) after Conv2D, PReLU() after Dense:
+     * the P/R/O-Net layers of the MTCNN detector behind detectors/face_detector.py:63-78): y = v > 0 ? v : prelu[c] * v,
+     * applied to conv + bias.  Not combined with resid / relu / accumulate. */
+    const float* prelu;
 } fn_conv_desc;
 
 /* One Inception-ResNet-B block ("Block17", inception_resnet_v1.py:153-204) of the BN-FOLDED inference network in ONE launch:
@@ -191,6 +195,32 @@ int fn_bn_relu_train_bwd(void* dz, int ld_d, const void* y, int ld_y, int M, int
 int fn_maxpool3x3s2_fwd(const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, uint8_t* argmax, int dtype, void* stream);
 int fn_maxpool3x3s2_bwd(const void* x, int ld_x, const void* dy, int ld_dy, void* dx, int ld_dx, int N, int H, int W, int C,
                         const uint8_t* argmax, int accumulate, int dtype, void* stream);
+/* ---- MTCNN face detector (detectors/face_detector.py:63-78 wraps PyPI `mtcnn`; apps/extract_faces.py:30,56) -------------
+ * The P/R/O-Net convolutions and dense layers are fn_conv2d_fwd launches (bias + fn_conv_desc.prelu); these three entry points
+ * are the rest of the device work.  Arithmetic restated in oracle/mtcnn_oracle.py (parity unpinned: the package and cv2 are
+ * not installed).
+ * fn_area_resize_crop: for k < n, boxes[4k..] = (ox, oy, cw, ch) is a crop of the uint8 HWC frame (zero outside the frame),
+ *   resized to OH x OW like cv2.resize(crop, (OW, OH), interpolation=cv2.INTER_AREA) -- true area resampling when both axes
+ *   shrink, cv2's area-mode bilinear otherwise -- then (v - 127.5) * 0.0078125 and stored TRANSPOSED as out[k][x][y][8] low
+ *   precision (channels 3..7 zero): the networks were trained on transposed images.  source_is_u8 = 1: the crop is a uint8
+ *   image (float accumulators, result rounded half-to-even to uint8: the stage-1 pyramid); 0: the crop is float64 (stages 2, 3:
+ *   double accumulators, no rounding; the enlarging path is only built for this case). */
+int fn_area_resize_crop(const uint8_t* frame, int H, int W, const int32_t* boxes, int n, int OH, int OW, int source_is_u8, void* out,
+                        int dtype, void* stream);
+/* MaxPooling2D(pool_size=k, strides=stride, 'valid' or 'same'): pad_h / pad_w = Keras' padding BEFORE (0 for every MTCNN
+ * layer), windows are clipped at the border, OH / OW as Keras computes them. */
+int fn_maxpool2d_fwd(const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, int k, int stride, int pad_h, int pad_w,
+                     int OH, int OW, int dtype, void* stream);
+/* P-Net map [ncell][ld] fp32 = (logit0, logit1, reg0..3, ...) per cell: p1 = softmax(logits)[1]; cells with p1 >= threshold are
+ * appended to cand as 6 floats (cell index as int bits, p1, reg0..3) in any order; *counter = number of hits (may exceed
+ * max_cand: only the first max_cand are stored). */
+int fn_mtcnn_candidates(const float* map, long ncell, int ld, float threshold, float* cand, int32_t* counter, int max_cand, void* stream);
+/* Greedy NMS of the package (__nms): boxes [n][ld] float64 rows (x1, y1, x2, y2, ...), order = np.argsort(scores) (ascending; the
+ * best box is order[n-1]), ratio = inter / (area_i + area_j - inter) or, by_min, inter / min(area_i, area_j), all in float64 with
+ * the package's operation order; a box survives while every better kept box has ratio <= threshold.  keep[0..*n_keep) = indices
+ * of the kept boxes, best first.  workspace: n * ceil(n / 64) * 8 bytes (pairwise bit matrix). */
+int fn_nms_greedy(const double* boxes, int ld, const int32_t* order, int n, double threshold, int by_min, void* workspace,
+                  long workspace_bytes, int32_t* keep, int32_t* n_keep, void* stream);
 int fn_avgpool_fwd(const void* x, void* y, int N, int HW, int C, int dtype, void* stream);
 int fn_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype, void* stream);
 
