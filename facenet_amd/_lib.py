@@ -73,7 +73,9 @@ _SIGNATURES = {
     "fn_maxpool3x3s2_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p],
     "fn_area_resize_crop": [_p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p],
     "fn_maxpool2d_fwd": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
-    "fn_mtcnn_candidates": [_p, C.c_long, _i, _f, _p, _p, _i, _p],
+    "fn_area_resize_frame": [_p, _i, _i, _i, _i, _p, _p, _i, _p],
+    "fn_mtcnn_candidates": [_p, C.c_long, _i, _f, _p, _p, _i, _i, _i, _p],
+    "fn_nms_greedy_batch": [_p, _i, _p, _p, _p, _p, _i, _p, C.c_long, _p, _p, _p],
     "fn_nms_greedy": [_p, _i, _p, _i, C.c_double, _i, _p, C.c_long, _p, _p, _p],
     "fn_avgpool_fwd": [_p, _p, _i, _i, _i, _i, _p],
     "fn_avgpool_bwd": [_p, _p, _i, _i, _i, _i, _p],

@@ -149,6 +149,70 @@ __global__ __launch_bounds__(256) void area_resize_crop_kernel(const uint8_t* __
     }
 }
 
+// Whole-frame pyramid level in two passes -- the order cv2's resizeArea_ itself works in: every source row is first reduced
+// horizontally (buf[dx] += S[sx] * alpha, table order), then the rows of one destination row are combined (sum = beta * buf,
+// sum += beta * buf).  Same arithmetic, bit for bit, as area_resize_crop_kernel<T, float>, but H x OW and OH x OW threads with
+// loops of <= scale entries instead of OH x OW threads with loops of scale^2 pixels (the small levels of a 1280x720 pyramid
+// reduce 52 x 52 pixels per output: 130 us per level in the one-pass kernel).
+__global__ __launch_bounds__(256) void area_rows_kernel(const uint8_t* __restrict__ frame, int H, int W, int OW, float* __restrict__ rows) {
+#pragma clang fp contract(off)
+    const long total = (long)H * OW;
+    const double scale_x = 1.0 / ((double)OW / W);
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int dx = (int)(t % OW), sy = (int)(t / OW);
+        const AreaSpan xs = area_span(dx, W, scale_x);
+        const uint8_t* S = frame + (long)sy * W * 3;
+        float buf[3] = {0.f, 0.f, 0.f};
+        if (xs.lead >= 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) buf[c] = buf[c] + (float)S[xs.lead * 3 + c] * xs.a_lead;
+        }
+        for (int sx = xs.s1; sx < xs.s2; ++sx) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) buf[c] = buf[c] + (float)S[sx * 3 + c] * xs.a_full;
+        }
+        if (xs.trail >= 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) buf[c] = buf[c] + (float)S[xs.trail * 3 + c] * xs.a_trail;
+        }
+        float* o = rows + t * 3;
+        o[0] = buf[0]; o[1] = buf[1]; o[2] = buf[2];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void area_cols_kernel(const float* __restrict__ rows, int H, int OH, int OW, unsigned short* __restrict__ out) {
+#pragma clang fp contract(off)
+    const long total = (long)OH * OW;
+    const double scale_y = 1.0 / ((double)OH / H);
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int dx = (int)(t % OW), dy = (int)(t / OW);     // consecutive threads read consecutive row entries
+        const AreaSpan ys = area_span(dy, H, scale_y);
+        float r[3] = {0.f, 0.f, 0.f};
+        bool first = true;
+        const int ny = (ys.lead >= 0) + (ys.s2 - ys.s1) + (ys.trail >= 0);
+        for (int j = 0; j < ny; ++j) {
+            int sy; float beta;
+            if (ys.lead >= 0 && j == 0) { sy = ys.lead; beta = ys.a_lead; }
+            else {
+                const int jj = j - (ys.lead >= 0);
+                if (jj < ys.s2 - ys.s1) { sy = ys.s1 + jj; beta = ys.a_full; }
+                else { sy = ys.trail; beta = ys.a_trail; }
+            }
+            const float* b = rows + ((long)sy * OW + dx) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) r[c] = first ? beta * b[c] : r[c] + beta * b[c];
+            first = false;
+        }
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (fminf(fmaxf(rintf(r[c]), 0.f), 255.f) - 127.5f) * 0.0078125f;
+#pragma unroll
+        for (int c = 3; c < 8; ++c) v[c] = 0.f;
+        *reinterpret_cast<u32x4*>(out + ((long)dx * OH + dy) * 8) = pack8<T>(v);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2d_fwd_kernel(const unsigned short* __restrict__ x, int ld_x, unsigned short* __restrict__ y, int ld_y,
                                                             int N, int H, int W, int C, int k, int stride, int pad_h, int pad_w, int OH, int OW) {
@@ -177,10 +241,11 @@ __global__ __launch_bounds__(256) void maxpool2d_fwd_kernel(const unsigned short
 }
 
 // P-Net output map, one row of `ld` floats per cell: [logit0, logit1, reg0..reg3, ...].  Keras Softmax(axis=3) in fp32:
-// e = exp(l - max(l)); p1 = e1 / (e0 + e1).  Cells with p1 >= threshold are appended (any order) as
-// (cell index, p1, reg0..reg3); *counter counts every hit, also those beyond max_cand (the host then reruns with more room).
+// e = exp(l - max(l)); p1 = e1 / (e0 + e1).  Cells with p1 >= threshold are appended (any order) as 8-float records
+// (cell index, tag, p1, reg0..reg3, 0); `tag` names the pyramid level, so all levels of a frame share one buffer and one
+// counter.  *counter counts every hit, also those beyond max_cand (the host then reruns with more room).
 __global__ __launch_bounds__(256) void mtcnn_candidates_kernel(const float* __restrict__ map, long ncell, int ld, float threshold,
-                                                               float* __restrict__ cand, int* __restrict__ counter, int max_cand) {
+                                                               float* __restrict__ cand, int* __restrict__ counter, int max_cand, int tag) {
 #pragma clang fp contract(off)
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < ncell; t += (long)gridDim.x * 256) {
         const float* r = map + t * ld;
@@ -191,26 +256,37 @@ __global__ __launch_bounds__(256) void mtcnn_candidates_kernel(const float* __re
         if (p1 >= threshold) {
             const int slot = atomicAdd(counter, 1);
             if (slot < max_cand) {
-                float* o = cand + (long)slot * 6;
-                o[0] = __int_as_float((int)t);
-                o[1] = p1;
-                o[2] = r[2]; o[3] = r[3]; o[4] = r[4]; o[5] = r[5];
+                f32x4* o = reinterpret_cast<f32x4*>(cand + (long)slot * 8);
+                o[0] = f32x4{__int_as_float((int)t), __int_as_float(tag), p1, r[2]};
+                o[1] = f32x4{r[3], r[4], r[5], 0.f};
             }
         }
     }
 }
-
 
 // ---- greedy non-maximum suppression (the package's __nms) ----------------------------------------------------------------
 // Candidates are visited in rank order (rank r = box order[n-1-r]: the host's np.argsort of the scores, best first); a visited
 // box that is still alive is kept and removes every later box whose overlap ratio o fails `o <= threshold`.  The O(n^2) part --
 // all pairwise ratios, in float64 with the package's operation order (no contraction) -- is one bit matrix; the inherently
 // serial part is a scan that resolves 64 ranks at a time inside one wave and ORs the kept rows into the `removed` bit set.
-__global__ __launch_bounds__(64) void nms_mask_kernel(const double* __restrict__ boxes, int ld, const int32_t* __restrict__ order, int n,
-                                                      double threshold, int by_min, unsigned long long* __restrict__ mask, int W) {
+struct NmsJobs {          // up to 16 independent jobs per launch; boxes / order / keep are concatenated in job order
+    int n[16], off[16], by_min[16];
+    long ws_off[16];      // in 8-byte words
+    double thr[16];
+};
+
+__global__ __launch_bounds__(64) void nms_mask_kernel(const double* __restrict__ boxes_all, int ld, const int32_t* __restrict__ order_all, NmsJobs jobs,
+                                                      unsigned long long* __restrict__ ws) {
 #pragma clang fp contract(off)
+    const int job = blockIdx.z;
+    const int n = jobs.n[job], W = (n + 63) / 64;
     const int rb = blockIdx.y, cb = blockIdx.x, t = threadIdx.x;
-    if (cb < rb) return;
+    if (cb >= W || rb >= W || cb < rb) return;
+    const double* boxes = boxes_all + (long)jobs.off[job] * ld;
+    const int32_t* order = order_all + jobs.off[job];
+    unsigned long long* mask = ws + jobs.ws_off[job];
+    const double threshold = jobs.thr[job];
+    const int by_min = jobs.by_min[job];
     __shared__ double sx1[64], sy1[64], sx2[64], sy2[64], sar[64];
     const int cj = cb * 64 + t;
     if (cj < n) {
@@ -237,10 +313,23 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const double* __restrict__
     mask[(long)i * W + cb] = bits;
 }
 
-__global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int W, const int32_t* __restrict__ order,
-                                                       int32_t* __restrict__ keep, int32_t* __restrict__ n_keep) {
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// One workgroup per job.  Ranks are resolved 64 at a time: lane l of wave 0 holds the diagonal word of rank b*64+l (which later
+// ranks OF THE SAME BLOCK it removes); the 64-step dependency chain runs on the scalar unit (v_readlane with constant lanes,
+// SGPR bit sets), then all 256 threads OR the kept rows into the `removed` words of the later blocks.
+__global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long* __restrict__ ws, const int32_t* __restrict__ order_all, NmsJobs jobs,
+                                                       int32_t* __restrict__ keep_all, int32_t* __restrict__ n_keep) {
     extern __shared__ unsigned long long removed[];
     __shared__ unsigned long long s_kept;
+    const int job = blockIdx.x;
+    const int n = jobs.n[job], W = (n + 63) / 64;
+    const unsigned long long* mask = ws + jobs.ws_off[job];
+    const int32_t* order = order_all + jobs.off[job];
+    int32_t* keep = keep_all + jobs.off[job];
     const int tid = threadIdx.x;
     for (int w = tid; w < W; w += 256) removed[w] = 0;
     int count = 0;   // meaningful in wave 0
@@ -249,12 +338,17 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long*
         if (tid < 64) {
             const int row = b * 64 + tid;
             const unsigned long long diag = row < n ? mask[(long)row * W + b] : 0ull;
-            unsigned long long rem = removed[b];
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            unsigned long long rem = uniform64(removed[b]);
             if (n - b * 64 < 64) rem |= ~0ull << (n - b * 64);       // ranks beyond n do not exist
             unsigned long long kept = 0;
-            for (int t = 0; t < 64; ++t) {
-                const unsigned long long d = __shfl(diag, t);
-                if (!((rem >> t) & 1ull)) { kept |= 1ull << t; rem |= d; }
+            if (rem != ~0ull) {
+#pragma unroll
+                for (int t = 0; t < 64; ++t) {
+                    const unsigned long long d = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, t) << 32) |
+                                                 (unsigned)__builtin_amdgcn_readlane((int)dlo, t);
+                    if (!((rem >> t) & 1ull)) { kept |= 1ull << t; rem |= d; }
+                }
             }
             if ((kept >> tid) & 1ull) keep[count + __popcll(kept & ((1ull << tid) - 1ull))] = order[n - 1 - row];
             count += __popcll(kept);
@@ -262,18 +356,20 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long*
         }
         __syncthreads();
         const unsigned long long kept = s_kept;
-        for (int w = b + 1 + tid; w < W; w += 256) {
-            unsigned long long acc = 0, k = kept;
-            while (k) {
-                const int t = __ffsll((long long)k) - 1;
-                k &= k - 1;
-                acc |= mask[(long)(b * 64 + t) * W + w];
+        if (kept) {
+            for (int w = b + 1 + tid; w < W; w += 256) {
+                unsigned long long acc = 0, k = kept;
+                while (k) {
+                    const int t = __ffsll((long long)k) - 1;
+                    k &= k - 1;
+                    acc |= mask[(long)(b * 64 + t) * W + w];
+                }
+                removed[w] |= acc;
             }
-            removed[w] |= acc;
         }
         __syncthreads();
     }
-    if (tid == 0) *n_keep = count;
+    if (tid == 0) n_keep[job] = count;
 }
 
 static inline int grid_of(long items, int cap = 8192) {
@@ -316,22 +412,55 @@ extern "C" int fn_maxpool2d_fwd(const void* x, int ld_x, void* y, int ld_y, int 
     return check_launch("maxpool2d");
 }
 
-extern "C" int fn_mtcnn_candidates(const float* map, long ncell, int ld, float threshold, float* cand, int32_t* counter, int max_cand, void* stream) {
+extern "C" int fn_mtcnn_candidates(const float* map, long ncell, int ld, float threshold, float* cand, int32_t* counter, int max_cand, int tag,
+                                   int reset_counter, void* stream) {
     FN_REQUIRE(map && cand && counter && ncell > 0 && ld >= 6 && ld % 2 == 0 && max_cand > 0, "mtcnn_candidates: bad arguments");
+    FN_REQUIRE(((uintptr_t)cand & 15) == 0, "mtcnn_candidates: cand must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    fill_words((unsigned*)counter, 0u, 0u, 1, st);
-    hipLaunchKernelGGL(mtcnn_candidates_kernel, dim3(grid_of(ncell)), dim3(256), 0, st, map, ncell, ld, threshold, cand, (int*)counter, max_cand);
+    if (reset_counter) fill_words((unsigned*)counter, 0u, 0u, 1, st);
+    hipLaunchKernelGGL(mtcnn_candidates_kernel, dim3(grid_of(ncell)), dim3(256), 0, st, map, ncell, ld, threshold, cand, (int*)counter, max_cand, tag);
     return check_launch("mtcnn_candidates");
+}
+
+extern "C" int fn_nms_greedy_batch(const double* boxes, int ld, const int32_t* order, const int32_t* sizes, const double* thresholds, const int32_t* by_min,
+                                   int njobs, void* workspace, long workspace_bytes, int32_t* keep, int32_t* n_keep, void* stream) {
+    FN_REQUIRE(boxes && order && sizes && thresholds && by_min && workspace && keep && n_keep && njobs > 0 && ld >= 4, "nms_greedy: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    long off = 0;
+    for (int j0 = 0; j0 < njobs; j0 += 16) {
+        NmsJobs jobs = {};
+        const int nj = njobs - j0 < 16 ? njobs - j0 : 16;
+        long words = 0;
+        int wmax = 0;
+        for (int j = 0; j < nj; ++j) {
+            const int n = sizes[j0 + j];
+            FN_REQUIRE(n > 0 && n <= (1 << 19), "nms_greedy: job %d has %d boxes", j0 + j, n);
+            const int W = (n + 63) / 64;
+            jobs.n[j] = n; jobs.off[j] = (int)off; jobs.by_min[j] = by_min[j0 + j]; jobs.thr[j] = thresholds[j0 + j]; jobs.ws_off[j] = words;
+            words += (long)n * W;
+            off += n;
+            wmax = W > wmax ? W : wmax;
+        }
+        FN_REQUIRE(words * 8 <= workspace_bytes, "nms_greedy: workspace of %ld bytes is too small (%ld needed)", workspace_bytes, words * 8);
+        FN_REQUIRE(wmax <= 65535, "nms_greedy: too many boxes in one job");
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(wmax, wmax, nj), dim3(64), 0, st, boxes, ld, order, jobs, (unsigned long long*)workspace);
+        hipLaunchKernelGGL(nms_scan_kernel, dim3(nj), dim3(256), (size_t)wmax * 8, st, (const unsigned long long*)workspace, order, jobs, keep, n_keep + j0);
+    }
+    return check_launch("nms_greedy");
 }
 
 extern "C" int fn_nms_greedy(const double* boxes, int ld, const int32_t* order, int n, double threshold, int by_min, void* workspace,
                              long workspace_bytes, int32_t* keep, int32_t* n_keep, void* stream) {
-    FN_REQUIRE(boxes && order && workspace && keep && n_keep && n > 0 && ld >= 4, "nms_greedy: bad arguments");
-    const int W = (n + 63) / 64;
-    FN_REQUIRE((long)n * W * 8 <= workspace_bytes, "nms_greedy: workspace of %ld bytes is too small for n=%d (%ld needed)", workspace_bytes, n, (long)n * W * 8);
-    FN_REQUIRE(W * 8 <= 64 * 1024, "nms_greedy: n=%d exceeds the scan's bit set (524288 boxes)", n);
+    return fn_nms_greedy_batch(boxes, ld, order, &n, &threshold, &by_min, 1, workspace, workspace_bytes, keep, n_keep, stream);
+}
+
+extern "C" int fn_area_resize_frame(const uint8_t* frame, int H, int W, int OH, int OW, float* rows, void* out, int dtype, void* stream) {
+    FN_REQUIRE(frame && rows && out && H > 0 && W > 0 && OH > 0 && OW > 0, "area_resize_frame: bad arguments");
+    FN_REQUIRE(OH <= H && OW <= W, "area_resize_frame: %dx%d -> %dx%d enlarges the uint8 frame (cv2's fixed-point bilinear path is not built)", H, W, OH, OW);
+    FN_REQUIRE(dtype == DT_BF16 || dtype == DT_F16, "area_resize_frame: dtype %d", dtype);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(W, W), dim3(64), 0, st, boxes, ld, order, n, threshold, by_min, (unsigned long long*)workspace, W);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(256), (size_t)W * 8, st, (const unsigned long long*)workspace, n, W, order, keep, n_keep);
-    return check_launch("nms_greedy");
+    hipLaunchKernelGGL(area_rows_kernel, dim3(grid_of((long)H * OW)), dim3(256), 0, st, frame, H, W, OW, rows);
+    if (dtype == DT_F16) hipLaunchKernelGGL((area_cols_kernel<_Float16>), dim3(grid_of((long)OH * OW)), dim3(256), 0, st, (const float*)rows, H, OH, OW, (unsigned short*)out);
+    else hipLaunchKernelGGL((area_cols_kernel<__bf16>), dim3(grid_of((long)OH * OW)), dim3(256), 0, st, (const float*)rows, H, OH, OW, (unsigned short*)out);
+    return check_launch("area_resize_frame");
 }

@@ -2,8 +2,8 @@
 `from mtcnn.mtcnn import MTCNN; MTCNN().detect_faces(image)`), same constructor arguments, same result format.
 
 Device work (libfacenet_hip.so, no CPU fallback): the image pyramid and the 24x24 / 48x48 candidate crops
-(`fn_area_resize_crop` = zero-padded crop + cv2 INTER_AREA + normalisation + transpose in one pass over the uint8 frame, which
-stays resident in HBM), the P / R / O networks (`fn_conv2d_fwd` with bias + PReLU epilogue for every Conv2D and Dense,
+(`fn_area_resize_frame` / `fn_area_resize_crop` = zero-padded crop + cv2 INTER_AREA + normalisation + transpose straight from
+the uint8 frame, which stays resident in HBM), the P / R / O networks (`fn_conv2d_fwd` with bias + PReLU epilogue for every Conv2D and Dense,
 `fn_maxpool2d_fwd`; both heads of a network are ONE convolution), and the P-Net softmax / threshold / compaction
 (`fn_mtcnn_candidates`).  Stage 1 launches the whole pyramid back to back and synchronises once.
 Greedy NMS: score order from the host's np.argsort, pairwise ratios + suppression scan on the device (`fn_nms_greedy`, float64).
@@ -171,24 +171,26 @@ class _DeviceNms:
                 out[k] = _iou_keep(b, thr, by_min)
         if not dev:
             return out
-        sizes = [jobs[k][0].shape[0] for k in dev]
-        offs = np.concatenate([[0], np.cumsum(sizes)])
-        boxes = np.ascontiguousarray(np.concatenate([jobs[k][0][:, :5] for k in dev], axis=0), dtype=np.float64)
-        order = np.concatenate([np.argsort(jobs[k][0][:, 4]) for k in dev]).astype(np.int32)
-        need = max(n * ((n + 63) // 64) * 8 for n in sizes)
+        sizes = np.asarray([jobs[k][0].shape[0] for k in dev], np.int32)
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        total = int(offs[-1])
+        # one upload: float64 boxes (x1, y1, x2, y2, score) followed by the int32 score orders
+        blob = np.empty(total * 40 + total * 4, np.uint8)
+        blob[:total * 40].view(np.float64).reshape(total, 5)[:] = np.concatenate([jobs[k][0][:, :5] for k in dev], axis=0)
+        blob[total * 40:].view(np.int32)[:] = np.concatenate([np.argsort(jobs[k][0][:, 4]) for k in dev])
+        need = int(sum(int(n) * ((int(n) + 63) // 64) * 8 for n in sizes))
         if self.ws is None or self.ws.numel() < need:
             self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        d_boxes, d_order = torch.from_numpy(boxes).to(self.device), torch.from_numpy(order).to(self.device)
-        d_keep = torch.empty(int(offs[-1]) + len(dev), dtype=torch.int32, device=self.device)
-        for j, k in enumerate(dev):
-            o, n = int(offs[j]), sizes[j]
-            _lib.check(lib.fn_nms_greedy(d_boxes.data_ptr() + o * 40, 5, d_order.data_ptr() + o * 4, n, float(jobs[k][1]), 1 if jobs[k][2] else 0,
-                                         self.ws.data_ptr(), self.ws.numel(), d_keep.data_ptr() + o * 4, d_keep.data_ptr() + (int(offs[-1]) + j) * 4, st),
-                       "nms_greedy")
+        d_blob = torch.from_numpy(blob).to(self.device)
+        d_keep = torch.empty(total + len(dev), dtype=torch.int32, device=self.device)
+        thr = np.asarray([jobs[k][1] for k in dev], np.float64)
+        by_min = np.asarray([1 if jobs[k][2] else 0 for k in dev], np.int32)
+        _lib.check(lib.fn_nms_greedy_batch(d_blob.data_ptr(), 5, d_blob.data_ptr() + total * 40, sizes.ctypes.data, thr.ctypes.data, by_min.ctypes.data, len(dev),
+                                           self.ws.data_ptr(), self.ws.numel(), d_keep.data_ptr(), d_keep.data_ptr() + total * 4, st), "nms_greedy")
         keep = d_keep.cpu().numpy()
         for j, k in enumerate(dev):
             o = int(offs[j])
-            out[k] = keep[o:o + int(keep[int(offs[-1]) + j])].astype(np.int64)
+            out[k] = keep[o:o + int(keep[total + j])].astype(np.int64)
         return out
 
 
@@ -267,7 +269,7 @@ class MTCNN:
         return scales
 
     def _pyramid(self, height, width):
-        key = (height, width, self._min_face_size, self._scale_factor, self._max_cand)
+        key = (height, width, self._min_face_size, self._scale_factor)
         if key not in self._pyr:
             levels = []
             pnet = self._nets["pnet"]
@@ -277,10 +279,10 @@ class MTCNN:
                     raise _lib.FacenetHipError("mtcnn: min_face_size < 12 enlarges the uint8 frame; that cv2 path is not built")
                 plan = pnet._plan(("pyr", i), 1, ws, hs)
                 oa, ob = plan["out"].shape[1:3]
-                levels.append({"scale": scale, "ws": ws, "hs": hs, "plan": plan, "A": oa, "B": ob,
-                               "cand": torch.empty(self._max_cand, 6, dtype=torch.float32, device=self.device)})
-            self._pyr[key] = {"levels": levels, "count": torch.zeros(max(len(levels), 1), dtype=torch.int32, device=self.device),
-                              "window": torch.tensor([[0, 0, width, height]], dtype=torch.int32, device=self.device)}
+                levels.append({"scale": scale, "ws": ws, "hs": hs, "plan": plan, "A": oa, "B": ob})
+            # one record buffer for all levels; row 0 is the header (word 0 = hit counter), so header + records leave in one copy
+            self._pyr[key] = {"levels": levels, "rec": torch.zeros(1 + self._max_cand, 8, dtype=torch.float32, device=self.device),
+                              "rows": torch.empty(height * max([lv["ws"] for lv in levels] + [1]) * 3, dtype=torch.float32, device=self.device)}
         return self._pyr[key]
 
     def pnet_maps(self, frame, level):
@@ -289,54 +291,71 @@ class MTCNN:
         H, W = frame.shape[:2]
         pyr = self._pyramid(H, W)
         lv = pyr["levels"][level]
-        cand = torch.empty(lv["A"] * lv["B"], 6, dtype=torch.float32, device=self.device)
-        self._run_level(frame, pyr, level, st, threshold=-1.0, cand=cand)     # threshold below every probability: all cells
-        torch.cuda.synchronize(self.device)
-        c = cand.cpu().numpy()
-        order = np.argsort(c[:, 0].view(np.int32))
-        c = c[order]
-        return c[:, 2:6].reshape(lv["A"], lv["B"], 4), c[:, 1].reshape(lv["A"], lv["B"])
+        rec = torch.zeros(1 + lv["A"] * lv["B"], 8, dtype=torch.float32, device=self.device)
+        self._run_level(frame, pyr, level, st, rec, threshold=-1.0, reset=True)     # threshold below every probability: all cells
+        c = rec[1:].cpu().numpy()
+        c = c[np.argsort(c[:, 0].copy().view(np.int32))]
+        return c[:, 3:7].reshape(lv["A"], lv["B"], 4), c[:, 2].reshape(lv["A"], lv["B"])
 
-    def _run_level(self, frame, pyr, i, st, threshold=None, cand=None):
+    def _run_level(self, frame, pyr, i, st, rec, threshold=None, reset=False):
         lib = _lib.load()
         lv = pyr["levels"][i]
         H, W = frame.shape[:2]
         pnet = self._nets["pnet"]
-        _lib.check(lib.fn_area_resize_crop(_ptr(frame), H, W, _ptr(pyr["window"]), 1, lv["hs"], lv["ws"], 1, _ptr(lv["plan"]["x"]), pnet.code, st),
-                   "area_resize_crop")
+        _lib.check(lib.fn_area_resize_frame(_ptr(frame), H, W, lv["hs"], lv["ws"], _ptr(pyr["rows"]), _ptr(lv["plan"]["x"]), pnet.code, st), "area_resize_frame")
         out = pnet.run(lv["plan"], 1, st)
-        cand = lv["cand"] if cand is None else cand
         _lib.check(lib.fn_mtcnn_candidates(_ptr(out), lv["A"] * lv["B"], pnet.out_channels, float(self._steps_threshold[0] if threshold is None else threshold),
-                                           _ptr(cand), _ptr(pyr["count"][i:]), cand.shape[0], st), "mtcnn_candidates")
+                                           _ptr(rec) + 32, _ptr(rec), rec.shape[0] - 1, i, 1 if reset else 0, st), "mtcnn_candidates")
         return out
 
     def _stage1(self, frame):
         H, W = frame.shape[:2]
         pyr = self._pyramid(H, W)
-        st = torch.cuda.current_stream(self.device).cuda_stream
-        outs = [self._run_level(frame, pyr, i, st) for i in range(len(pyr["levels"]))]
-        counts = pyr["count"].cpu().numpy()          # the one synchronisation of the stage
+        levels = pyr["levels"]
+        if not levels:
+            return np.empty((0, 9))
+        while True:
+            # the pyramid is a fixed launch sequence per frame size (11 levels x 9 launches at 1280x720): captured once as a
+            # HIP graph over a resident copy of the frame, replayed per frame
+            if "graph" not in pyr:
+                if "frame" not in pyr:
+                    pyr["frame"] = torch.empty_like(frame)
+                pyr["frame"].copy_(frame)
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    st = torch.cuda.current_stream(self.device).cuda_stream
+                    pyr["outs"] = [self._run_level(pyr["frame"], pyr, i, st, pyr["rec"], reset=(i == 0)) for i in range(len(levels))]
+                pyr["graph"] = g
+            pyr["frame"].copy_(frame)
+            pyr["graph"].replay()
+            outs = pyr["outs"]
+            first = min(pyr["rec"].shape[0], 1 + 2048)
+            head = pyr["rec"][:first].cpu().numpy()          # the one synchronisation of the launches above: counter + first records
+            n = int(head[0, 0:1].view(np.int32)[0])
+            if n <= pyr["rec"].shape[0] - 1:
+                break
+            # more hits than room: the levels are deterministic, run them again into a buffer that fits
+            pyr["rec"] = torch.zeros(1 + (1 << int(n - 1).bit_length()), 8, dtype=torch.float32, device=self.device)
+            del pyr["graph"]
+        c = head[1:1 + n] if n < first else np.concatenate([head[1:], pyr["rec"][first:1 + n].cpu().numpy()], axis=0)
+        cell, tag = c[:, 0].copy().view(np.int32), c[:, 1].copy().view(np.int32)
+        order = np.lexsort((cell, tag))                       # compaction order is arbitrary: back to level, then the package's scan order
+        c, cell, tag = c[order], cell[order], tag[order]
+        bounds = np.searchsorted(tag, np.arange(len(levels) + 1))
         per_level = []
-        for i, lv in enumerate(pyr["levels"]):
-            n = int(counts[i])
-            if n == 0:
+        for i, lv in enumerate(levels):
+            lo, hi = int(bounds[i]), int(bounds[i + 1])
+            if hi == lo:
                 continue
-            if n > lv["cand"].shape[0]:      # more hits than room: the level is deterministic, run it again into a buffer that fits
-                lv["cand"] = torch.empty(1 << int(n - 1).bit_length(), 6, dtype=torch.float32, device=self.device)
-                outs[i] = self._run_level(frame, pyr, i, st)
-                n = int(pyr["count"][i].item())
-            c = lv["cand"][:n].cpu().numpy()
-            cell = c[:, 0].copy().view(np.int32)
-            order = np.argsort(cell, kind="stable")           # compaction order is arbitrary: back to the package's scan order
-            cell, c = cell[order], c[order]
-            a, b = cell // lv["B"], cell % lv["B"]            # a: image x cell, b: image y cell
-            reg = c[:, 2:6]
-            if n == 1:   # package quirk: with exactly one cell the offsets are read from the map flipped along x
+            a, b = cell[lo:hi] // lv["B"], cell[lo:hi] % lv["B"]            # a: image x cell, b: image y cell
+            reg = c[lo:hi, 3:7]
+            if hi - lo == 1:   # package quirk: with exactly one cell the offsets are read from the map flipped along x
                 reg = outs[i][0, lv["A"] - 1 - int(a[0]), int(b[0]), 2:6].cpu().numpy()[None]
             bb = np.stack([a, b], axis=1)
             q1 = np.fix((2 * bb + 1) / lv["scale"])
             q2 = np.fix((2 * bb + 12) / lv["scale"])
-            per_level.append(np.hstack([q1, q2, c[:, 1:2], reg]))
+            per_level.append(np.hstack([q1, q2, c[lo:hi, 2:3], reg]))
         keeps = self._nms.run([(boxes, 0.5, False) for boxes in per_level])
         total = np.concatenate([np.empty((0, 9))] + [boxes[keep] for boxes, keep in zip(per_level, keeps)], axis=0)
         if total.shape[0] == 0:
@@ -407,7 +426,8 @@ class MTCNN:
             arr = np.asarray(img)
             if arr.dtype != np.uint8:
                 raise InvalidImage("Image not valid: uint8 pixels expected.")
-            frame = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+            arr = np.ascontiguousarray(arr)
+            frame = torch.from_numpy(arr if arr.flags.writeable else arr.copy()).to(self.device)
         if frame.dim() != 3 or frame.shape[2] != 3:
             raise InvalidImage("Image not valid: [height, width, 3] expected.")
         s1 = self._stage1(frame)

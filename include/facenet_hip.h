@@ -211,16 +211,25 @@ int fn_area_resize_crop(const uint8_t* frame, int H, int W, const int32_t* boxes
  * layer), windows are clipped at the border, OH / OW as Keras computes them. */
 int fn_maxpool2d_fwd(const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, int k, int stride, int pad_h, int pad_w,
                      int OH, int OW, int dtype, void* stream);
+/* Whole-frame pyramid level (source_is_u8 case of fn_area_resize_crop with the window = the frame, same results bit for bit) in
+ * two passes, horizontal then vertical -- the order cv2 itself works in; rows: fp32 workspace [H][OW][3].  OH <= H, OW <= W. */
+int fn_area_resize_frame(const uint8_t* frame, int H, int W, int OH, int OW, float* rows, void* out, int dtype, void* stream);
 /* P-Net map [ncell][ld] fp32 = (logit0, logit1, reg0..3, ...) per cell: p1 = softmax(logits)[1]; cells with p1 >= threshold are
- * appended to cand as 6 floats (cell index as int bits, p1, reg0..3) in any order; *counter = number of hits (may exceed
- * max_cand: only the first max_cand are stored). */
-int fn_mtcnn_candidates(const float* map, long ncell, int ld, float threshold, float* cand, int32_t* counter, int max_cand, void* stream);
+ * appended to cand (16-byte aligned) as 8-float records (cell index as int bits, tag as int bits, p1, reg0..3, 0) in any order;
+ * `tag` lets the levels of a pyramid share one buffer.  *counter += number of hits (may exceed max_cand: only records below
+ * max_cand are stored); reset_counter: zero it first. */
+int fn_mtcnn_candidates(const float* map, long ncell, int ld, float threshold, float* cand, int32_t* counter, int max_cand, int tag,
+                        int reset_counter, void* stream);
 /* Greedy NMS of the package (__nms): boxes [n][ld] float64 rows (x1, y1, x2, y2, ...), order = np.argsort(scores) (ascending; the
  * best box is order[n-1]), ratio = inter / (area_i + area_j - inter) or, by_min, inter / min(area_i, area_j), all in float64 with
  * the package's operation order; a box survives while every better kept box has ratio <= threshold.  keep[0..*n_keep) = indices
- * of the kept boxes, best first.  workspace: n * ceil(n / 64) * 8 bytes (pairwise bit matrix). */
+ * of the kept boxes, best first.  workspace: n * ceil(n / 64) * 8 bytes (pairwise bit matrix).
+ * _batch: njobs independent jobs in one pair of launches (one workgroup scans each job); boxes / order / keep are concatenated in
+ * job order, sizes / thresholds / by_min are HOST arrays of njobs entries, n_keep[j] per job, workspace = sum of the jobs'. */
 int fn_nms_greedy(const double* boxes, int ld, const int32_t* order, int n, double threshold, int by_min, void* workspace,
                   long workspace_bytes, int32_t* keep, int32_t* n_keep, void* stream);
+int fn_nms_greedy_batch(const double* boxes, int ld, const int32_t* order, const int32_t* sizes, const double* thresholds, const int32_t* by_min,
+                        int njobs, void* workspace, long workspace_bytes, int32_t* keep, int32_t* n_keep, void* stream);
 int fn_avgpool_fwd(const void* x, void* y, int N, int HW, int C, int dtype, void* stream);
 int fn_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype, void* stream);
 

@@ -59,6 +59,14 @@ def test_pyramid_level_is_bit_exact(lib, hw, scale):
     assert got.shape == (1, ws, hs, 8)
     assert np.array_equal(got[0, :, :, :3].astype(np.float64), np.transpose(ref, (1, 0, 2)))
     assert not got[..., 3:].any()
+    # the two-pass whole-frame form the detector uses: same bits
+    ft = torch.from_numpy(img).cuda()
+    rows = torch.empty(hw[0] * ws * 3, dtype=torch.float32, device="cuda")
+    out = torch.full((1, ws, hs, 8), 7.0, dtype=torch.float16, device="cuda")
+    _lib.check(lib.fn_area_resize_frame(ptr(ft), hw[0], hw[1], hs, ws, ptr(rows), ptr(out), HF, stream()))
+    assert np.array_equal(out.cpu().numpy(), got)
+    with pytest.raises(ValueError):
+        _lib.check(lib.fn_area_resize_frame(ptr(ft), hw[0], hw[1], hw[0] + 1, ws, ptr(rows), ptr(out), HF, stream()))
 
 
 @pytest.mark.parametrize("size", [24, 48])
@@ -162,14 +170,14 @@ class GpuNets:
         lib = _lib.load()
         out = _gpu_net(self.det, "pnet", x)
         _, a, b, ld = out.shape
-        cand = torch.empty(a * b, 6, dtype=torch.float32, device="cuda")
+        cand = torch.empty(a * b, 8, dtype=torch.float32, device="cuda")
         cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
-        _lib.check(lib.fn_mtcnn_candidates(ptr(out), a * b, ld, -1.0, ptr(cand), ptr(cnt), a * b, stream()))
+        _lib.check(lib.fn_mtcnn_candidates(ptr(out), a * b, ld, -1.0, ptr(cand), ptr(cnt), a * b, 0, 1, stream()))
         assert int(cnt.item()) == a * b
         c = cand.cpu().numpy()
         c = c[np.argsort(c[:, 0].copy().view(np.int32))]
-        prob1 = c[:, 1].reshape(1, a, b)
-        return c[:, 2:6].reshape(1, a, b, 4), np.stack([1 - prob1, prob1], axis=-1)
+        prob1 = c[:, 2].reshape(1, a, b)
+        return c[:, 3:7].reshape(1, a, b, 4), np.stack([1 - prob1, prob1], axis=-1)
 
     def rnet(self, x):
         rows = _gpu_net(self.det, "rnet", x).reshape(x.shape[0], -1).cpu().numpy()
@@ -207,9 +215,9 @@ def test_candidate_compaction_is_complete(lib, detector):
     logit = np.log(np.clip(prob, 1e-6, 1 - 1e-6) / np.clip(1 - prob, 1e-6, 1))
     out[:, 1] = torch.from_numpy(logit.reshape(-1)).cuda()
     out[:, 2:6] = torch.from_numpy(reg.reshape(-1, 4)).cuda()
-    cand = torch.zeros(a * b, 6, dtype=torch.float32, device="cuda")
+    cand = torch.zeros(a * b, 8, dtype=torch.float32, device="cuda")
     cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
-    _lib.check(lib.fn_mtcnn_candidates(ptr(out), a * b, 8, 0.6, ptr(cand), ptr(cnt), a * b, stream()))
+    _lib.check(lib.fn_mtcnn_candidates(ptr(out), a * b, 8, 0.6, ptr(cand), ptr(cnt), a * b, 5, 1, stream()))
     n = int(cnt.item())
     c = cand[:n].cpu().numpy()
     cells = np.sort(c[:, 0].copy().view(np.int32))
@@ -218,13 +226,13 @@ def test_candidate_compaction_is_complete(lib, detector):
     p1 = e[:, 1] / e.sum(1)
     margin = np.abs(p1 - 0.6) > 1e-6
     expect = np.where(p1 >= 0.6)[0]
-    assert 0 < n < a * b and len(np.unique(cells)) == n
+    assert 0 < n < a * b and len(np.unique(cells)) == n and np.all(c[:, 1].copy().view(np.int32) == 5)
     assert np.array_equal(np.intersect1d(cells, np.where(margin)[0]), np.intersect1d(expect, np.where(margin)[0]))
     row = c[0]
     cell = int(row[0:1].view(np.int32)[0])
-    assert np.array_equal(row[2:6], out[cell, 2:6].cpu().numpy()) and abs(row[1] - p1[cell]) < 1e-6
-    _lib.check(lib.fn_mtcnn_candidates(ptr(out), a * b, 8, 0.6, ptr(cand), ptr(cnt), 5, stream()))   # room for 5 only
-    assert int(cnt.item()) == n
+    assert np.array_equal(row[3:7], out[cell, 2:6].cpu().numpy()) and abs(row[2] - p1[cell]) < 1e-6 and row[7] == 0
+    _lib.check(lib.fn_mtcnn_candidates(ptr(out), a * b, 8, 0.6, ptr(cand), ptr(cnt), 5, 5, 0, stream()))   # room for 5 only, counter carries on
+    assert int(cnt.item()) == 2 * n
 
 
 @pytest.mark.parametrize("hw,seed", [((120, 160), 1), ((201, 143), 2), ((96, 256), 3)])
@@ -309,3 +317,31 @@ def test_api_errors_and_wrappers(detector, weights, tmp_path):
     lists = {net: [weights[k] for k, _ in mo.variable_shapes(net)] for net in ("pnet", "rnet", "onet")}
     back = gm.weights_from_lists(lists)
     assert set(back) == set(weights) and all(np.array_equal(back[k], weights[k]) for k in weights)
+
+
+def test_extract_faces_app(detector, weights, tmp_path):
+    """apps/extract_faces.py:37-80: thumbnails per class, `_n` suffix for further faces, single-face filter, unreadable files counted."""
+    from types import SimpleNamespace
+
+    from PIL import Image
+
+    from facenet_amd.apps.extract_faces import extract_faces
+    src = tmp_path / "in" / "alice"
+    src.mkdir(parents=True)
+    Image.fromarray(_frame(120, 160, seed=1)).save(src / "a.png")
+    Image.fromarray(np.zeros((11, 30, 3), np.uint8)).save(src / "tiny.png")     # no pyramid level: no face
+    (src / "broken.jpg").write_bytes(b"not an image")
+    path = tmp_path / "w.npz"
+    np.savez(path, **weights)
+    fd = FaceDetector(detector="pypimtcnn", weights_file=str(path))
+    cls = SimpleNamespace(name="alice", files=sorted(str(p) for p in src.iterdir()))
+    opts = SimpleNamespace(size=160, margin=0.25)
+    out = tmp_path / "out"
+    stats = extract_faces([cls], out, fd, opts, detect_multiple_faces=True, log=lambda *a: None)
+    n = len(detector.detect_faces(_frame(120, 160, seed=1)))
+    assert n > 1 and stats["extracted"] == 1 and stats["unread"] == 1 and len(stats["sizes"]) == n
+    names = sorted(p.name for p in (out / "alice").iterdir())
+    assert "a.png" in names and f"a_{n - 1}.png" in names and len(names) == n
+    assert Image.open(out / "alice" / "a.png").size == (200, 200) and (out / "sizes.json").exists()
+    single = extract_faces([cls], tmp_path / "out1", fd, opts, detect_multiple_faces=False, log=lambda *a: None)
+    assert single["extracted"] == 0 and not list((tmp_path / "out1" / "alice").iterdir())

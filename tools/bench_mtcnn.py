@@ -53,7 +53,7 @@ def main():
     e0.record()
     for _ in range(10):
         for i in range(len(pyr["levels"])):
-            det._run_level(frames[0], pyr, i, st)
+            det._run_level(frames[0], pyr, i, st, pyr["rec"], reset=(i == 0))
     e1.record(); torch.cuda.synchronize()
     out = {"metric": "MTCNN detect_faces, 1280x720 frames", "value": round(a.frames / dt, 2), "unit": "frames/sec", "ms_per_frame": round(1e3 * dt / a.frames, 2),
            "ms_split": {k: round(1e3 * v / a.frames, 2) for k, v in split.items()}, "stage1_device_ms": round(e0.elapsed_time(e1) / 10, 3),
