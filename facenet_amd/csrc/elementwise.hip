@@ -189,15 +189,28 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* 
     float sc[8], sf[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = s_scale[tx * 8 + e]; sf[e] = s_shift[tx * 8 + e]; }
-    for (int r = r0 + ty; r < r1; r += TY) {
-        float v[8];
-        unpack8<T>(r == r0 + ty ? pre : *reinterpret_cast<const u32x4*>(y + (long)r * ld_y + c), v);
+    // four rows per trip: the loads of a trip are all in flight before the first is used (the big stem maps give a thread 8+ rows;
+    // one row per trip is one exposed memory latency per row)
+    for (int r = r0 + ty; r < r1; r += 4 * TY) {
+        u32x4 in[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float zf = fmaf(v[e], sc[e], sf[e]);
-            v[e] = relu ? fmaxf(zf, 0.f) : zf;
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * TY;
+            if (rr < r1) in[u] = (u == 0 && r == r0 + ty) ? pre : *reinterpret_cast<const u32x4*>(y + (long)rr * ld_y + c);
         }
-        *reinterpret_cast<u32x4*>(z + (long)r * ld_z + c) = pack8<T>(v);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * TY;
+            if (rr >= r1) break;
+            float v[8];
+            unpack8<T>(in[u], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float zf = fmaf(v[e], sc[e], sf[e]);
+                v[e] = relu ? fmaxf(zf, 0.f) : zf;
+            }
+            *reinterpret_cast<u32x4*>(z + (long)rr * ld_z + c) = pack8<T>(v);
+        }
     }
 }
 
@@ -229,16 +242,29 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const unsigned 
         float b[8], sc[8], sf[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { b[e] = beta[c + e]; sc[e] = scale[c + e]; sf[e] = shift[c + e]; }
-        for (int r = r0 + ty; r < r1; r += TY) {
-            float g[8], yy[8];
-            unpack8<T>(*reinterpret_cast<const u32x4*>(dz + (long)r * ld_d + c), g);
-            unpack8<T>(*reinterpret_cast<const u32x4*>(y + (long)r * ld_y + c), yy);
+        for (int r = r0 + ty; r < r1; r += 4 * TY) {
+            u32x4 ig[4], iy[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float zf = fmaf(yy[e], sc[e], sf[e]);
-                const float gg = (!relu || zf > 0.f) ? g[e] : 0.f;
-                a1[e] += gg;
-                a2[e] += gg * (zf - b[e]);
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * TY;
+                if (rr < r1) {
+                    ig[u] = *reinterpret_cast<const u32x4*>(dz + (long)rr * ld_d + c);
+                    iy[u] = *reinterpret_cast<const u32x4*>(y + (long)rr * ld_y + c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (r + u * TY >= r1) break;
+                float g[8], yy[8];
+                unpack8<T>(ig[u], g);
+                unpack8<T>(iy[u], yy);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float zf = fmaf(yy[e], sc[e], sf[e]);
+                    const float gg = (!relu || zf > 0.f) ? g[e] : 0.f;
+                    a1[e] += gg;
+                    a2[e] += gg * (zf - b[e]);
+                }
             }
         }
     }
@@ -319,19 +345,32 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(unsigned short* 
     for (int e = 0; e < 8; ++e) {
         k1[e] = s_k1[tx * 8 + e]; k2[e] = s_k2[tx * 8 + e]; sc[e] = scale[c + e]; sf[e] = shift[c + e]; bt[e] = beta[c + e];
     }
-    for (int r = r0 + ty; r < r1; r += TY) {
-        unsigned short* p = dz + (long)r * ld_d + c;
-        float g[8], yy[8];
-        const bool first = r == r0 + ty;
-        unpack8<T>(first ? pre_g : *reinterpret_cast<const u32x4*>(p), g);
-        unpack8<T>(first ? pre_y : *reinterpret_cast<const u32x4*>(y + (long)r * ld_y + c), yy);
+    for (int r = r0 + ty; r < r1; r += 4 * TY) {      // four rows per trip, all loads first (see bn_relu_fwd_kernel)
+        u32x4 ig[4], iy[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float zf = fmaf(yy[e], sc[e], sf[e]);
-            const float gg = (!relu || zf > 0.f) ? g[e] : 0.f;
-            g[e] = sc[e] * (gg - k1[e] - (zf - bt[e]) * k2[e]);
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * TY;
+            if (rr < r1) {
+                const bool first = u == 0 && r == r0 + ty;
+                ig[u] = first ? pre_g : *reinterpret_cast<const u32x4*>(dz + (long)rr * ld_d + c);
+                iy[u] = first ? pre_y : *reinterpret_cast<const u32x4*>(y + (long)rr * ld_y + c);
+            }
         }
-        *reinterpret_cast<u32x4*>(p) = pack8<T>(g);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * TY;
+            if (rr >= r1) break;
+            float g[8], yy[8];
+            unpack8<T>(ig[u], g);
+            unpack8<T>(iy[u], yy);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float zf = fmaf(yy[e], sc[e], sf[e]);
+                const float gg = (!relu || zf > 0.f) ? g[e] : 0.f;
+                g[e] = sc[e] * (gg - k1[e] - (zf - bt[e]) * k2[e]);
+            }
+            *reinterpret_cast<u32x4*>(dz + (long)rr * ld_d + c) = pack8<T>(g);
+        }
     }
 }
 

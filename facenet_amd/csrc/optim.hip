@@ -54,10 +54,44 @@ __global__ void adam_tick_kernel(float* hyper, float beta1, float beta2) {
 template <typename T>
 __global__ __launch_bounds__(256) void pack_transpose_kernel(const unsigned short* __restrict__ w, unsigned short* __restrict__ wt,
                                                              const int* __restrict__ table) {
-    __shared__ unsigned short tile[32][33];
+    __shared__ __attribute__((aligned(16))) unsigned short tile64[64][72];
+    unsigned short (*tile)[33] = reinterpret_cast<unsigned short (*)[33]>(&tile64[0][0]);
     const int* row = table + 8 * blockIdx.y;
     const long off = row[0];
     const int cout = row[1], taps = row[3], cin = row[4];
+    if ((cout & 7) == 0) {
+        // 64 x 64 tiles moved in 16-byte pieces on both sides (cin and cout are multiples of 8 for every layer but an odd-sized
+        // classifier): 8 ci per load along a [co] row, 8 co gathered from LDS per store along a [ci] row
+        const int tco = (cout + 63) >> 6, tci = (cin + 63) >> 6;
+        const int ntiles = taps * tco * tci;
+        for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+            const int tap = t / (tco * tci), r = t - tap * tco * tci;
+            const int co0 = (r / tci) << 6, ci0 = (r % tci) << 6;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = threadIdx.x + 256 * i, rr = idx >> 3, ch = idx & 7;
+                const int co = co0 + rr, ci = ci0 + ch * 8;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (co < cout && ci < cin) v = *reinterpret_cast<const u32x4*>(w + off + ((long)co * taps + tap) * cin + ci);
+                *reinterpret_cast<u32x4*>(&tile64[rr][ch * 8]) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = threadIdx.x + 256 * i, rr = idx >> 3, ch = idx & 7;     // rr: ci row, ch: group of 8 co
+                const int ci = ci0 + rr, co = co0 + ch * 8;
+                if (ci < cin && co < cout) {
+                    u32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = (unsigned)tile64[ch * 8 + 2 * e][rr] | ((unsigned)tile64[ch * 8 + 2 * e + 1][rr] << 16);
+                    *reinterpret_cast<u32x4*>(wt + off + ((long)ci * taps + tap) * cout + co) = v;
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     const int tco = (cout + 31) >> 5, tci = (cin + 31) >> 5;
     const int ntiles = taps * tco * tci;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
@@ -86,11 +120,15 @@ __global__ __launch_bounds__(256) void fold_bn_kernel(const float* __restrict__ 
     const int* row = table + 8 * blockIdx.y;
     const long off = row[0];
     const int cout = row[1], ktot = row[2], bn = row[5], fb = row[6];
-    const long total = (long)cout * ktot;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int co = (int)(i / ktot);
+    // 8 weights per thread (ktot and the layer offsets are multiples of 8: channels are padded to 8): two 16-byte loads, one
+    // 16-byte store and ONE integer division per 8 elements
+    const int total8 = (int)(((long)cout * ktot) >> 3);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total8; i += gridDim.x * 256) {
+        const int co = (i << 3) / ktot;
         const float s = bn >= 0 ? rsqrtf(mv[bn + co] + eps) : 1.f;
-        wf[off + i] = LP<T>::from_f32(w[off + i] * s);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(w + off + ((long)i << 3)), b = *reinterpret_cast<const f32x4*>(w + off + ((long)i << 3) + 4);
+        const float v[8] = {a[0] * s, a[1] * s, a[2] * s, a[3] * s, b[0] * s, b[1] * s, b[2] * s, b[3] * s};
+        *reinterpret_cast<u32x4*>(wf + off + ((long)i << 3)) = pack8<T>(v);
     }
     if (bn >= 0 && fb >= 0 && blockIdx.x == 0)
         for (int co = threadIdx.x; co < cout; co += 256) {

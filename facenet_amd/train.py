@@ -356,6 +356,23 @@ class Trainer:
         grp = (lambda ops: group_wgrads(group_convs(ops, self.net), self.net)) if self.group_wgrad else (lambda ops: list(ops))
         self.segments: List[Tuple[Optional[Schedule], Optional[Tuple[int, int]]]] = []
         if not self.segmented:
+            chunks = int(os.environ.get("FACENET_WGRAD_CHUNKS", "0"))
+            if chunks > 0 and self.group_wgrad:
+                # experiment: the weight gradients leave the critical path -- the backward is cut into `chunks` pieces, each piece's
+                # weight gradients become grouped launches pinned to a SIDE stream (they only feed the optimiser), everything else
+                # stays on the main stream; the dgrad chain is latency-bound at a few % of the wave slots, the side stream fills them
+                marks = [i for i, op in enumerate(self.plan.bwd) if op.name.startswith("conv_wgrad:")]
+                cuts = [0] + [marks[len(marks) * k // chunks] for k in range(1, chunks)] + [len(self.plan.bwd)]
+                ops: List[Op] = []
+                for k in range(chunks):
+                    ops += grp((head if k == 0 else []) + self.plan.bwd[cuts[k]:cuts[k + 1]])
+                ops += self.opt_ops
+                for op in ops:
+                    op.stream_hint = 1 if op.name.startswith("conv_wgrad") else 0
+                self.n_streams = max(2, self.n_streams)
+                self.streams = _streams_for(self.net, self.n_streams)
+                self.segments.append((Schedule(ops, self.n_streams), None))
+                return
             self.segments.append((Schedule(grp(head + self.plan.bwd) + self.opt_ops, self.n_streams), None))
             return
         pos, first = 0, True
