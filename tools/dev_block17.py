@@ -1,6 +1,6 @@
 """Microbenchmark of fn_block17_infer: whole block and (FN_B17_STOP=k) its first k stages; graph replay of 20 launches."""
 import os, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from facenet_amd import _lib
 lib = _lib.load()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 180
@@ -26,3 +26,4 @@ for _ in range(3):
     a.record(); gr.replay(); b.record(); torch.cuda.synchronize()
     best = min(best, a.elapsed_time(b) * 1e3 / 20)
 print(f"N={N} stop={os.environ.get('FN_B17_STOP', '0')}: {best:7.2f} us per launch")
+
