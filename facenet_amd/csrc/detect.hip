@@ -325,6 +325,7 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long*
                                                        int32_t* __restrict__ keep_all, int32_t* __restrict__ n_keep) {
     extern __shared__ unsigned long long removed[];
     __shared__ unsigned long long s_kept;
+    __shared__ int s_list[64];
     const int job = blockIdx.x;
     const int n = jobs.n[job], W = (n + 63) / 64;
     const unsigned long long* mask = ws + jobs.ws_off[job];
@@ -333,12 +334,15 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long*
     const int tid = threadIdx.x;
     for (int w = tid; w < W; w += 256) removed[w] = 0;
     int count = 0;   // meaningful in wave 0
+    unsigned long long diag = tid < 64 && tid < n ? mask[(long)tid * W] : 0ull;      // diagonal word of block 0
     __syncthreads();
     for (int b = 0; b < W; ++b) {
         if (tid < 64) {
             const int row = b * 64 + tid;
-            const unsigned long long diag = row < n ? mask[(long)row * W + b] : 0ull;
             const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            // the next block's diagonal does not depend on this block's outcome: request it now, use it after the barriers
+            const int nrow = row + 64;
+            if (b + 1 < W) diag = nrow < n ? mask[(long)nrow * W + b + 1] : 0ull;
             unsigned long long rem = uniform64(removed[b]);
             if (n - b * 64 < 64) rem |= ~0ull << (n - b * 64);       // ranks beyond n do not exist
             unsigned long long kept = 0;
@@ -350,22 +354,21 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long*
                     if (!((rem >> t) & 1ull)) { kept |= 1ull << t; rem |= d; }
                 }
             }
-            if ((kept >> tid) & 1ull) keep[count + __popcll(kept & ((1ull << tid) - 1ull))] = order[n - 1 - row];
+            if ((kept >> tid) & 1ull) {
+                const int pos = __popcll(kept & ((1ull << tid) - 1ull));
+                keep[count + pos] = order[n - 1 - row];
+                s_list[pos] = tid;
+            }
             count += __popcll(kept);
             if (tid == 0) s_kept = kept;
         }
         __syncthreads();
-        const unsigned long long kept = s_kept;
-        if (kept) {
-            for (int w = b + 1 + tid; w < W; w += 256) {
-                unsigned long long acc = 0, k = kept;
-                while (k) {
-                    const int t = __ffsll((long long)k) - 1;
-                    k &= k - 1;
-                    acc |= mask[(long)(b * 64 + t) * W + w];
-                }
-                removed[w] |= acc;
-            }
+        // every (kept rank, later word) pair is one independent load + LDS atomic: one memory round trip per block of 64 ranks
+        const int nk = __popcll(s_kept), wrem = W - b - 1;
+        for (int idx = tid; idx < nk * wrem; idx += 256) {
+            const int ki = idx / wrem, w = b + 1 + (idx - ki * wrem);
+            const unsigned long long m = mask[(long)(b * 64 + s_list[ki]) * W + w];
+            if (m) atomicOr(&removed[w], m);
         }
         __syncthreads();
     }

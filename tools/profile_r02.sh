@@ -8,6 +8,8 @@ O=$R/gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
 export FACENET_TUNE_CACHE=$O/r02_tile_cache.json
+# keep the committed tile choices when there are some (RETUNE=1 times the variants afresh): tuning is noisy at the 1 % level
+if [ -z "$RETUNE" ] && [ -f $R/profiles/r02_tile_cache.json ]; then cp $R/profiles/r02_tile_cache.json $FACENET_TUNE_CACHE; fi
 cd /tmp
 echo "[1] default bench (100 steps, CPU legs)"; python3 $R/bench.py > $O/r02_bench_default.json 2> $O/r02_bench_default.err || exit 1
 tail -c 400 $O/r02_bench_default.json; echo
