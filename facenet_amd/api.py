@@ -56,9 +56,6 @@ class FaceNet:
         return self._model.embedding_size
 
     def evaluate(self, images):
-        import torch
-        from . import _lib
-        from .engine import _ptr
         emb = self._model(images, training=False)
         if not self._normalized:   # un-normalised bottleneck (BN output in inference mode)
             n = emb.shape[0]

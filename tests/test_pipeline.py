@@ -216,6 +216,14 @@ def test_training_apps_from_a_directory_data_set(tmp_path):
         labels.append(lab.cpu().numpy())
     emb = np.concatenate([np.asarray(e.cpu() if torch.is_tensor(e) else e) for e in embs])
     assert emb.shape == (100, 128) and np.allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-3)
+    # the un-normalised branch (facenet/__init__.py:74-77 with config.normalize false: the bottleneck tensor itself)
+    raw_api = FaceNet(Config({"path": str(ckpt), "normalize": False, "embedding_size": 128}))
+    x8 = np.random.default_rng(3).integers(0, 256, (8, 160, 160, 3), dtype=np.uint8)
+    raw, unit = raw_api.evaluate(x8), api.evaluate(x8)
+    norms = np.linalg.norm(raw, axis=1)
+    assert raw.shape == (8, 128) and not np.allclose(norms, 1, atol=1e-2)
+    assert np.allclose(raw / np.maximum(norms[:, None], 1e-10), unit, atol=2e-3)
+    assert raw_api.image_to_embedding(x8[0]).shape == (1, 128)
     # triplet path fed by the P x K sampler (20 classes x 5 images per pool)
     pipe = dataset.pipeline_with_equal_batches(loader, db.classes, cfg, workers=4)
     logs2 = []
