@@ -494,7 +494,11 @@ class Lowering:
         self.fuse_residual_bwd = bool(int(os.environ.get("FACENET_FUSE_RESIDUAL_BWD", "1")))
         # Inference / mining plans: a whole Block17 (five convolution launches) runs as ONE launch with its tower activations in
         # LDS (fn_block17_infer, csrc/block_fused.hip).  BatchNorm is folded there, so nothing couples the images of a batch.
-        self.fuse_blocks = bool(int(os.environ.get("FACENET_FUSE_BLOCKS", "1")))
+        # One workgroup per image: below ~32 images the fused kernels leave most of the chip idle and the layer-wise launches win
+        # (tools/bench_inference.py, batch 1 / 8 / 32: 0.91 / 0.97 / 1.09 ms fused against 0.80 / 0.86 / 1.06 ms layer-wise);
+        # FACENET_FUSE_BLOCKS = 0 never, 1 from FACENET_FUSE_BLOCKS_MIN_BATCH (32) images up.
+        self.fuse_blocks = bool(int(os.environ.get("FACENET_FUSE_BLOCKS", "1"))) and \
+            (declare or N >= int(os.environ.get("FACENET_FUSE_BLOCKS_MIN_BATCH", "32")))
         self.virtual: Dict[str, List[Tuple[int, int]]] = {}     # buffer -> [(c0, C)] BN ranges that are not materialised
         self.dtype = net.train_dtype if training else net.infer_dtype
         self.dt = None if declare else _lib.dtype_code(self.dtype)
