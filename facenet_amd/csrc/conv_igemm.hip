@@ -970,6 +970,12 @@ static bool valid_tile(int t) {
 // In-launch split-K factor for the 32-row tiles: long k chains on few workgroups (see conv_igemm_body).
 static int choose_conv_ks(int M, int NOUT, int KTOT, int bm, int bn) {
     static const int force = getenv("FN_CONV_KS") ? atoi(getenv("FN_CONV_KS")) : 0;   // tuning aid
+    if (bm == 64) {   // 64-row tiles on grids of at most one workgroup per CU (block17 1x7 / 7x1, block35 3x3 at batch 90: 180 workgroups, 9-14 k
+                      // tiles): a second wave per SIMD halves the k chain -- 13.6 -> 10.2 us per launch, step 7.06 -> 7.01 ms; larger grids
+                      // (FN_CONV_KS64=400 / 640) and 128-wide tiles measured no gain
+        static const int ks64 = getenv("FN_CONV_KS64") ? atoi(getenv("FN_CONV_KS64")) : 256;   // largest grid that splits (0: never)
+        return (force != 1 && bn <= 64 && cdiv(KTOT, 64) >= 8 && (long)cdiv(M, 64) * cdiv(NOUT, bn) <= ks64) ? 2 : 1;
+    }
     if (bm != 32) return 1;
     const long blocks = (long)cdiv(M, 32) * cdiv(NOUT, bn);
     const int ntk = cdiv(KTOT, 64);
@@ -986,7 +992,8 @@ static int choose_conv_ks(int M, int NOUT, int KTOT, int bm, int bn) {
 // tile variants: BM, BN, waves (M x N), register stages, split-K groups
 #define FN_CONV_VARIANTS(X) X(128, 128, 2, 2, 1, 1) X(128, 64, 2, 2, 2, 1) X(128, 32, 4, 1, 2, 1) X(64, 128, 1, 4, 2, 1) X(64, 64, 2, 2, 2, 1) \
     X(64, 32, 2, 2, 2, 1) X(32, 128, 1, 4, 4, 1) X(32, 64, 1, 4, 4, 1) X(32, 32, 2, 2, 4, 1)                                           \
-    X(32, 128, 1, 4, 4, 2) X(32, 64, 1, 4, 4, 2) X(32, 64, 1, 4, 4, 4) X(32, 32, 2, 2, 4, 2) X(32, 32, 2, 2, 4, 4)
+    X(32, 128, 1, 4, 4, 2) X(32, 64, 1, 4, 4, 2) X(32, 64, 1, 4, 4, 4) X(32, 32, 2, 2, 4, 2) X(32, 32, 2, 2, 4, 4)                       \
+    X(64, 64, 2, 2, 2, 2) X(64, 32, 2, 2, 2, 2)
 
 // variant code: BM*1000 + BN (+ KS*1000000 when KS > 1)
 static int variant_code(int bm, int bn, int ks) { return bm * 1000 + bn + (ks > 1 ? ks * 1000000 : 0); }

@@ -45,7 +45,7 @@ def test_halo_cases_dispatch_to_the_halo_kernel(lib):
         d.x = d.w = d.y = d.dx = ptr(t)
         assert lib.fn_conv2d_variant(C.byref(d), 0) >= 9000000 and lib.fn_conv2d_variant(C.byref(d), 1) >= 9000000
         d.tile_fwd = d.tile_dgrad = 64064
-        assert lib.fn_conv2d_variant(C.byref(d), 0) == 64064 and lib.fn_conv2d_variant(C.byref(d), 1) == 64064
+        assert lib.fn_conv2d_variant(C.byref(d), 0) % 1000000 == 64064 and lib.fn_conv2d_variant(C.byref(d), 1) % 1000000 == 64064   # (+ 2e6: in-launch split-K)
     d = conv_desc(2, 17, 17, 32, 32, 3, 3, 1, 1, 1, _lib.FN_BF16)          # small map: implicit GEMM
     d.x = d.w = d.y = d.dx = ptr(torch.zeros(16, device="cuda"))
     assert lib.fn_conv2d_variant(C.byref(d), 0) < 9000000
