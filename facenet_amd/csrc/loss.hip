@@ -94,11 +94,24 @@ __global__ __launch_bounds__(1024) void select_pairs_kernel(const int* __restric
     int cnt = 0;
     if (tid < n)
         for (int p = tid + 1; p < n; ++p) cnt += (s_lab[p] == s_lab[tid]);
-    if (tid < n) s_off[tid + 1] = cnt;
-    if (tid == 0) s_off[0] = 0;
-    __syncthreads();
-    if (tid == 0)
-        for (int i = 0; i < n; ++i) s_off[i + 1] += s_off[i];
+    // inclusive prefix of the per-anchor counts: wave scan + carry of the wave totals (a serial loop of thread 0 over the n entries
+    // was ~7 us of dependent LDS round trips)
+    {
+        __shared__ int s_wtot[16];
+        const int lane = tid & 63, wv = tid >> 6;
+        int v = tid < n ? cnt : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int u = __shfl_up(v, d);
+            if (lane >= d) v += u;
+        }
+        if (lane == 63) s_wtot[wv] = v;
+        __syncthreads();
+        int carry = 0;
+        for (int w = 0; w < wv; ++w) carry += s_wtot[w];
+        if (tid < n) s_off[tid + 1] = v + carry;
+        if (tid == 0) s_off[0] = 0;
+    }
     __syncthreads();
     if (tid < n) {
         int q = s_off[tid];
@@ -162,12 +175,23 @@ __global__ __launch_bounds__(1024) void select_rank_kernel(int T, int* __restric
     const int tid = threadIdx.x;
     const int* rec = info + 8;
     const int Q = info[0];
+    // (cls, key) of the first 4096 pairs staged in LDS as one 64-bit sort key: the O(Q^2) comparison loop then reads LDS, not global
+    __shared__ unsigned long long s_key[4096];
+    for (int q = tid; q < min(Q, 4096); q += 1024)
+        s_key[q] = ((unsigned long long)(unsigned)rec[5 * q + 4] << 32) | (unsigned)rec[5 * q + 3];
+    __syncthreads();
     // rank by (cls, key, q); rank < T wins slot `rank`
     for (int q = tid; q < Q; q += 1024) {
         const int cls = rec[5 * q + 4];
         const unsigned key = (unsigned)rec[5 * q + 3];
+        const unsigned long long mine = ((unsigned long long)(unsigned)cls << 32) | key;
         int rank = 0;
-        for (int r = 0; r < Q; ++r) {
+        const int QL = min(Q, 4096);
+        for (int r = 0; r < QL; ++r) {
+            const unsigned long long k2 = s_key[r];
+            rank += (k2 < mine || (k2 == mine && r < q)) ? 1 : 0;
+        }
+        for (int r = QL; r < Q; ++r) {
             const int c2 = rec[5 * r + 4];
             const unsigned k2 = (unsigned)rec[5 * r + 3];
             const bool before = (c2 < cls) || (c2 == cls && (k2 < key || (k2 == key && r < q)));
