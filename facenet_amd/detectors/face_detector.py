@@ -31,9 +31,10 @@ class BoundingBox:
         self.confidence = confidence
 
     def info(self, mode=False):
-        if mode is False:
-            return '{}'.format([self.left, self.top, self.width, self.height, self.confidence])
-        return "left = {}, top = {}, width = {}, height = {}, confidence = {}".format(self.left, self.top, self.width, self.height, self.confidence)
+        fields = [self.left, self.top, self.width, self.height, self.confidence]
+        if mode:
+            return "left = {}, top = {}, width = {}, height = {}, confidence = {}".format(*fields)
+        return str(fields)
 
     __repr__ = lambda self: self.info(mode=True)
     left_upper = property(lambda self: (self.left, self.top))
@@ -57,18 +58,16 @@ class FaceDetector:
     """face_detector.py:98-123; `detector='pypimtcnn'` is the only one built (keyword arguments go to the MTCNN constructor)."""
 
     def __init__(self, detector='pypimtcnn', gpu_memory_fraction=1.0, **kwargs):
-        self.detector = detector
-        if self.detector == 'pypimtcnn':
-            obj = MTCNN(**kwargs)
-        elif self.detector == 'frcnnv3':
+        if detector == 'frcnnv3':
             raise NotImplementedError("frcnnv3 (frozen Faster-RCNN graph, weights absent from the reference) is out of scope")
-        else:
-            raise ValueError('Undefined face detector type {}'.format(self.detector))
-        self.mode = obj.mode
-        self.__detector = obj.detector
+        if detector != 'pypimtcnn':
+            raise ValueError('Undefined face detector type {}'.format(detector))
+        backend = MTCNN(**kwargs)
+        self.detector, self.mode, self._find = detector, backend.mode, backend.detector
 
     def detect(self, image):
-        return self.__detector(image)
+        """image: uint8 array [height, width, 3] in `self.mode` channel order -> list of BoundingBox."""
+        return self._find(image)
 
     def __repr__(self):
-        return f'class {self.__class__.__name__}\ndetector type: {self.detector}'
+        return f'class {type(self).__name__}\ndetector type: {self.detector}'
