@@ -981,9 +981,11 @@ static int choose_conv_ks(int M, int NOUT, int KTOT, int bm, int bn) {
     const int ntk = cdiv(KTOT, 64);
     // measured (tools/dev_ksweep.py): the chain costs ~0.16 us per k tile only while a CU holds one workgroup; with 3+
     // workgroups per CU the loop is issue-bound and splitting K just adds the reduction
+    static const int lim2 = getenv("FN_CONV_KS32_2") ? atoi(getenv("FN_CONV_KS32_2")) : 128;   // tuning aids: largest grids that split
+    static const int lim4 = getenv("FN_CONV_KS32_4") ? atoi(getenv("FN_CONV_KS32_4")) : 64;
     int ks = 1;
-    if (ntk >= 8 && blocks <= 128) ks = 2;
-    if (ntk >= 16 && blocks <= 64 && bn <= 64) ks = 4;
+    if (ntk >= 8 && blocks <= lim2) ks = 2;
+    if (ntk >= 16 && blocks <= lim4 && bn <= 64) ks = 4;
     if (force == 1) ks = 1;
     if (force == 2 && ks > 2) ks = 2;
     return ks;
