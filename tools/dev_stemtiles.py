@@ -1,0 +1,45 @@
+"""Developer aid: the stem 3x3 layers (180 images, f16) under every implicit-GEMM tile (tile_fwd set per descriptor; FN_CONV_HALO=0 keeps
+the halo kernel out): does the time follow the operand bytes per tile (L2 -> CU bound) or the MFMA work?"""
+import ctypes as C, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("FN_CONV_HALO", "0")
+from facenet_amd import _lib
+from tests.util import conv_desc, ptr
+lib = _lib.load()
+R = 6
+
+
+def bench(name, N, H, W, Cin, Cout, s, tile, dt=_lib.FN_F16):
+    tdt = torch.float16
+    ds, keep = [], []
+    for r in range(R):
+        d = conv_desc(N, H, W, Cin, Cout, 3, 3, s, 0, 0, dt)
+        x = torch.randn(N, H, W, Cin, device='cuda').to(tdt)
+        w = (torch.randn(Cout, 3, 3, Cin, device='cuda') * 0.05).to(tdt)
+        y = torch.zeros(N, d.OH, d.OW, Cout, dtype=tdt, device='cuda')
+        b = torch.zeros(Cout, device='cuda')
+        d.x, d.w, d.y, d.bias, d.relu, d.tile_fwd = ptr(x), ptr(w), ptr(y), ptr(b), 1, tile
+        ds.append(d); keep.append((x, w, y, b))
+    cur = torch.cuda.current_stream().cuda_stream
+    for d in ds: _lib.check(lib.fn_conv2d_fwd(C.byref(d), cur))
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s_ = torch.cuda.current_stream().cuda_stream
+        for _ in range(3):
+            for d in ds: lib.fn_conv2d_fwd(C.byref(d), s_)
+    g.replay(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); g.replay(); e.record(); torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(e) * 1e3 / (3 * R))
+    fl = 2.0 * N * ds[0].OH * ds[0].OW * Cout * 9 * Cin
+    bm, bn = tile // 1000, tile % 1000
+    print(f"{name:10s} tile {bm:3d}x{bn:3d}: {best:7.2f} us {fl / best / 1e6:7.1f} TF/s   operand bytes per MFMA clock {(bm + bn) * 128 / (bm * bn / 32):5.1f}", flush=True)
+
+
+for name, shp in (("2b", (180, 77, 77, 32, 64, 1)), ("4a", (180, 37, 37, 80, 192, 1)), ("4b", (180, 35, 35, 192, 256, 2))):
+    for tile in (128128, 128064, 128032, 64128, 64064, 32032):
+        if tile % 1000 > 64 and shp[4] <= 64: continue
+        bench(name, *shp, tile)
