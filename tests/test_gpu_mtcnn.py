@@ -345,3 +345,24 @@ def test_extract_faces_app(detector, weights, tmp_path):
     assert Image.open(out / "alice" / "a.png").size == (200, 200) and (out / "sizes.json").exists()
     single = extract_faces([cls], tmp_path / "out1", fd, opts, detect_multiple_faces=False, log=lambda *a: None)
     assert single["extracted"] == 0 and not list((tmp_path / "out1" / "alice").iterdir())
+
+
+def test_detector_entry_points_reject_bad_arguments(lib):
+    """C-ABI error behaviour: rc = FN_EINVAL (-> ValueError) with a message, nothing launched."""
+    z8 = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    zf = torch.zeros(64, dtype=torch.float32, device="cuda")
+    zi = torch.zeros(64, dtype=torch.int32, device="cuda")
+    zd = torch.zeros(64, dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError):       # no boxes
+        _lib.check(lib.fn_area_resize_crop(ptr(z8), 4, 4, ptr(zi), 0, 24, 24, 0, ptr(zf), HF, stream()))
+    with pytest.raises(ValueError):       # unknown dtype
+        _lib.check(lib.fn_area_resize_crop(ptr(z8), 4, 4, ptr(zi), 1, 24, 24, 0, ptr(zf), 7, stream()))
+    with pytest.raises(ValueError):       # enlarging a uint8 frame
+        _lib.check(lib.fn_area_resize_frame(ptr(z8), 4, 4, 8, 4, ptr(zf), ptr(zf), HF, stream()))
+    with pytest.raises(ValueError):       # channels not a multiple of 8
+        _lib.check(lib.fn_maxpool2d_fwd(ptr(zf), 12, ptr(zf), 12, 1, 2, 2, 12, 2, 2, 0, 0, 1, 1, HF, stream()))
+    with pytest.raises(ValueError):       # record buffer not 16-byte aligned
+        _lib.check(lib.fn_mtcnn_candidates(ptr(zf), 4, 8, 0.5, ptr(zf) + 4, ptr(zi), 4, 0, 1, stream()))
+    with pytest.raises(ValueError):       # bit-matrix workspace too small: 100 boxes need 100 * 2 * 8 bytes
+        _lib.check(lib.fn_nms_greedy(ptr(zd), 5, ptr(zi), 100, 0.5, 0, ptr(zf), 64, ptr(zi), ptr(zi), stream()))
+    assert b"workspace" in lib.fn_last_error()
