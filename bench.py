@@ -314,6 +314,51 @@ def embedding_l2_err(dev):
     return out
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process (one rank per GPU, RCCL), let
+    it print rank 0's JSON line on our stdout, and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args):
+    """--dry-run: everything around the HIP work -- rendezvous (FACENET_DIST_BACKEND, default nccl = RCCL), barrier, MAX-over-ranks
+    timing reduction, one JSON line from rank 0 -- with a sleep instead of the step.  Lets the N > 1 launch path be tested on a box
+    without GPUs (tests/test_bench_launcher.py)."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("FACENET_DIST_BACKEND", "nccl"))
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.001 * args.steps)
+    el = time.perf_counter() - t0
+    ranks_seen = 1
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        ranks_seen = dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec (160x160 triplet train)", "value": None, "unit": "images/sec", "n_gpus": world,
+                          "dist_world_size": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
+                          "dry_run": True, "data": "none"}))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -327,18 +372,30 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the dependency scheduler may use (1 = serial)")
     ap.add_argument("--force-segments", action="store_true", help="1 GPU: run the data-parallel segment structure (6 buckets) without the all-reduce")
     ap.add_argument("--dump-ops", default=None, help="write per-launch HIP-event timings (eager) to this JSON file")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / reporting path only: no HIP work (CPU test of --gpus N)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.streams > 2 and not args.no_graph:
+        raise SystemExit("--streams > 2 needs --no-graph: captured schedules span at most 2 streams (DESIGN.md section 5)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD torch.distributed.run (never exec: this
+        # process must not be replaced once anything has touched the GPU, and nothing has yet -- no HIP call above this line)
+        sys.exit(launch_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or unset WORLD_SIZE and let "
+                         f"bench.py start the ranks)")
+    if args.dry_run:
+        return dry_run(args)
 
     # the tile choices of the committed profiles (profiles/r02_tile_cache.json: one autotune run on an MI355X) are reused when
     # present: the run then launches the kernel variants the rocprofv3 passes under profiles/ measured (roofline.traffic), starts
     # faster and is reproducible.  FACENET_TUNE_CACHE= (empty) re-tunes from scratch.
     if "FACENET_TUNE_CACHE" not in os.environ and os.path.exists(os.path.join(ROOT, "profiles", "r02_tile_cache.json")):
         os.environ["FACENET_TUNE_CACHE"] = os.path.join(ROOT, "profiles", "r02_tile_cache.json")
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # one process per GPU; FACENET_DIST_BACKEND=gloo lets the whole data-parallel path be rehearsed with several ranks on
     # ONE GPU (RCCL refuses two ranks on a device), which is how it is tested on the single-GPU development box
     backend = os.environ.get("FACENET_DIST_BACKEND", "nccl")
@@ -432,6 +489,8 @@ def main():
                        "global_batch": B * world, "image": "160x160x3 uint8", "embedding": E, "alpha": 0.2,
                        "optimizer": "Keras Adam eps=0.1 + L2 5e-4", "parallelism": f"dp{world}",
                        "hip_graph": not args.no_graph, "streams": args.streams},
+            "dist_world_size": torch.distributed.get_world_size() if world > 1 else 1,
+            "dist_backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None,
             "value_train_only": round(B * world * n2 / elapsed_train, 1),
             "ms_per_step_train_only": round(1e3 * elapsed_train / n2, 3),
             "loss_after_warmup": round(float(loss_warm), 5), "final_loss": round(loss, 5),
@@ -458,6 +517,12 @@ def main():
             out["embedding_l2_err"] = embedding_l2_err(dev)
             out["cpu_baseline"] = cpu_baseline(60, 30, reps=2) if args.cpu_sample else cpu_baseline()
     if world > 1:
+        # gradient exchange: per-bucket all-reduce time on the communication stream and how much of it backward hides
+        # (every rank runs the profiled steps -- they are collective; rank 0 reports its own view)
+        xp = trainer.exchange_profile(steps=3)
+        if rank == 0:
+            out["gradient_exchange"] = {**xp, "n_buckets": len(trainer.buckets), "dtype": "fp32", "op": "all_reduce(SUM), 1/world inside the optimiser",
+                                        "note": "HIP events on the communication stream; overlapped = share of all-reduce time before the compute stream finished backward"}
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:
@@ -465,4 +530,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -5,47 +5,65 @@ from __future__ import annotations
 from pathlib import Path
 
 
+_INDENT = "   "     # the reference prints nested sections three spaces deeper (facenet/config.py:72)
+
+
+def _wrap(value):
+    return Config(value) if isinstance(value, dict) else value
+
+
+def _unwrap(value):
+    return value.as_dict if isinstance(value, Config) else value
+
+
+def _lines(fields, depth):
+    """YAML-like listing of a field table: 'key: value' lines, a nested section as 'key: ' plus its own lines indented."""
+    for key, value in fields.items():
+        if isinstance(value, Config):
+            yield f"{_INDENT * depth}{key}: "
+            yield from _lines(value._fields, depth + 1)
+        else:
+            yield f"{_INDENT * depth}{key}: {value}"
+
+
 class Config:
+    """Settings tree with attribute access.  Contract of facenet/config.py:54-107: nested dicts become nested Configs, a
+    missing attribute reads as an empty (falsy) Config so that `if cfg.a.b.c:` never raises, attributes may be assigned,
+    `as_dict` / `items()` / `exists()` expose the fields.  The fields live in one private table instead of the instance
+    dictionary."""
+
+    __slots__ = ("_fields",)
+
     def __init__(self, dct=None):
-        if dct is None:
-            dct = dict()
-        for key, item in dct.items():
-            if isinstance(item, dict):
-                setattr(self, key, Config(item))
-            else:
-                setattr(self, key, item)
+        object.__setattr__(self, "_fields", {k: _wrap(v) for k, v in (dct or {}).items()})
 
-    def __repr__(self):
-        def get_str(obj, ident=""):
-            s = ""
-            for key, item in obj.items():
-                if isinstance(item, Config):
-                    s += f"{ident}{key}: \n{get_str(item, ident=ident + '   ')}"
-                else:
-                    s += f"{ident}{key}: {str(item)}\n"
-            return s
-        return get_str(self)
+    def __getattr__(self, name):            # only reached for names that are not slots / methods
+        if name.startswith("_"):            # copy / pickle protocol probes (and a missing field table) are real errors
+            raise AttributeError(name)
+        found = self._fields.get(name)
+        return Config() if found is None and name not in self._fields else found
 
-    def __getattr__(self, name):
-        return self.__dict__.get(name, Config())
+    def __setattr__(self, name, value):
+        self._fields[name] = _wrap(value)
+
+    def __reduce__(self):                   # copy / pickle rebuild through the constructor
+        return (Config, (self.as_dict,))
 
     def __bool__(self):
-        return bool(self.__dict__)
+        return len(self._fields) > 0
+
+    def __repr__(self):
+        return "".join(line + "\n" for line in _lines(self._fields, 0))
 
     @property
     def as_dict(self):
-        def as_dict(obj):
-            s = {}
-            for key, item in obj.items():
-                s[key] = as_dict(item) if isinstance(item, Config) else item
-            return s
-        return as_dict(self)
+        return {k: _unwrap(v) for k, v in self._fields.items()}
 
     def items(self):
-        return self.__dict__.items()
+        return self._fields.items()
 
     def exists(self, name):
-        return name in self.__dict__.keys()
+        return name in self._fields
 
 
 class LoadConfigError(Exception):

@@ -42,7 +42,6 @@ struct Block17Args {
     float scale;
     int relu;
     int N;
-    int debug_stop;                // tuning aid (FN_B17_STOP): return after this stage (1..3); outputs are then not written
 };
 
 __device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 2) & 1) << 1)) << 4); }
@@ -190,7 +189,6 @@ __global__ __launch_bounds__(512) void block17_infer_kernel(const Block17Args a)
         }
         __syncthreads();
     }
-    if (a.debug_stop == 1) return;
 
     // Stages 2-4 stream slabs of [128 columns][64 input channels]: 128-byte rows, 16-byte chunk XOR (row & 7) (the implicit-GEMM
     // kernel's B layout); a k tile is two MFMA k steps.  Loader role: row = tid >> 3 (+32 q), chunk = tid & 7.
@@ -315,7 +313,6 @@ __global__ __launch_bounds__(512) void block17_infer_kernel(const Block17Args a)
                 }
         }
         __syncthreads();
-        if (a.debug_stop == stage) return;
     }
 
     // ---------------- stage 4: out = act(x + scale * (mixed[64 x 256] * Wup[256 x 896] + bias)), 7 passes of 128 columns ----------------
@@ -692,17 +689,14 @@ extern "C" int fn_block17_infer(const void* x, void* y, int N, const void* w_t0,
                "block17_infer: bad arguments");
     Block17Args a{(const unsigned short*)x, (unsigned short*)y, (const unsigned short*)w_t0, (const unsigned short*)w_t1a,
                   (const unsigned short*)w_t1b, (const unsigned short*)w_t1c, (const unsigned short*)w_up, b_t0, b_t1a, b_t1b, b_t1c, b_up,
-                  scale, relu, N, getenv("FN_B17_STOP") ? atoi(getenv("FN_B17_STOP")) : 0};
+                  scale, relu, N};
     constexpr size_t smem = 8 * 64 * 64 + 2 * 4 * 112 * 64 + 3 * 16 * 1024;      // staging: 2 x 20 KB (register ring) or 3 x 16 KB (LDS-DMA)
     static const int use_dma = getenv("FN_B17_DMA") ? atoi(getenv("FN_B17_DMA")) : 1;   // measured: stages 2+3 12.4 -> 9.6 us per block (tools/dev_block17.py)
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block17_infer_kernel<__bf16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block17_infer_kernel<_Float16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block17_infer_kernel<__bf16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block17_infer_kernel<_Float16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static LdsOptIn ok[4];
+    const void* kerns[4] = {reinterpret_cast<const void*>(block17_infer_kernel<__bf16, false>), reinterpret_cast<const void*>(block17_infer_kernel<_Float16, false>),
+                            reinterpret_cast<const void*>(block17_infer_kernel<__bf16, true>), reinterpret_cast<const void*>(block17_infer_kernel<_Float16, true>)};
+    const int which = (use_dma ? 2 : 0) + (dtype == FN_BF16 ? 0 : 1);
+    if (int rc = allow_big_lds(kerns[which], ok[which], "block17_infer")) return rc;
     if (use_dma) {
         if (dtype == FN_BF16) hipLaunchKernelGGL((block17_infer_kernel<__bf16, true>), dim3(N), dim3(512), smem, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((block17_infer_kernel<_Float16, true>), dim3(N), dim3(512), smem, (hipStream_t)stream, a);
@@ -732,12 +726,10 @@ extern "C" int fn_block35_infer(const void* x, void* y, int N, const void* const
     constexpr int SLICE = 304 * 64, PATCH = (19 * 19 * 64 + 1023) / 1024 * 1024 + 1024;
     constexpr size_t smem = 3 * SLICE + 2 * PATCH + 2 * (SLICE + 96 * 64);
     static_assert(smem <= 160 * 1024 && 3 * 256 * 64 <= 2 * (SLICE + 96 * 64) && 304 * 36 * 4 <= 2 * PATCH, "block35 LDS plan");
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block35_infer_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block35_infer_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static LdsOptIn ok[2];
+    const int which = dtype == FN_BF16 ? 0 : 1;
+    if (int rc = allow_big_lds(which == 0 ? reinterpret_cast<const void*>(block35_infer_kernel<__bf16>) : reinterpret_cast<const void*>(block35_infer_kernel<_Float16>),
+                               ok[which], "block35_infer")) return rc;
     if (dtype == FN_BF16) hipLaunchKernelGGL(block35_infer_kernel<__bf16>, dim3(N), dim3(512), smem, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(block35_infer_kernel<_Float16>, dim3(N), dim3(512), smem, (hipStream_t)stream, a);
     return check_launch("block35_infer");

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace fn {
 
@@ -134,6 +135,28 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Kernels that ask for more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised first.  The
+// attribute is PER DEVICE: one flag per (launch site, device), set once, and a failing call is an error here rather than an
+// unrelated launch failure later.
+struct LdsOptIn {
+    std::atomic<bool> done[32];
+};
+static inline int allow_big_lds(const void* kernel, LdsOptIn& state, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) {
+        set_error("%s: no current HIP device (or more than 32 devices)", what);
+        return FN_ELAUNCH;
+    }
+    if (state.done[dev].load(std::memory_order_relaxed)) return FN_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize, 160 KiB) failed on device %d: %s", what, dev, hipGetErrorString(e));
+        return FN_ELAUNCH;
+    }
+    state.done[dev].store(true, std::memory_order_relaxed);
+    return FN_OK;
+}
 
 // Re-initialisation of small per-call state words (statistics, losses, min/max) inside launch functions that may be captured
 // into a HIP graph.  A kernel, not hipMemsetAsync: memset NODES of a replayed graph were observed (ROCm 7.2, MI355X) to be

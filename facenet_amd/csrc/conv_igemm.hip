@@ -833,11 +833,16 @@ static size_t halo_smem_bytes(int BN, int KH, int KW) {
 // (tools/dev_convbench.py halo, batch 90 / 180): Conv2d_2a 53 -> 35 / 89 -> 55 us, Conv2d_2b 61 -> 54 / 108 -> 93 us; Conv2d_4a
 // (80 -> 192 channels on 35 x 35: 36 % of the 8x16 tile slots fall outside the map and the weights are re-staged per slice) is
 // slower here (79 vs 65 us) and stays on the implicit-GEMM kernel.  FN_CONV_HALO=0 switches the kernel off (A/B measurements).
+enum { TILE_HALO = 9000000 };   // fn_conv_desc.tile_fwd / tile_dgrad: an explicit request for the halo-tile kernel
+static bool halo_capable(const ConvArgs& a) {   // what the kernel can compute at all
+    return !a.s2 && !a.plain && a.so == 1 && a.dshift == 0 && a.KH == 3 && a.KW == 3 && a.CS % 8 == 0 && !a.nrm_stats && a.nt_total == 0;
+}
 static bool halo_eligible(const ConvArgs& a) {
+    if (a.tile == TILE_HALO) return halo_capable(a);   // kernel tests cover it beyond the sizes where it wins
     static const int enabled = getenv("FN_CONV_HALO") ? atoi(getenv("FN_CONV_HALO")) : 1;
     static const int maxc = getenv("FN_CONV_HALO_MAXC") ? atoi(getenv("FN_CONV_HALO_MAXC")) : 64;
-    return enabled && !a.s2 && !a.plain && a.so == 1 && a.dshift == 0 && a.KH == 3 && a.KW == 3 && a.CS % 8 == 0 && a.CS <= maxc && a.PH >= 30 && a.PW >= 30 &&
-           !a.nrm_stats && a.nt_total == 0 && a.tile == 0;   // an explicit tile (fn_conv_desc.tile_*) asks for the implicit-GEMM kernel
+    return enabled && halo_capable(a) && a.CS <= maxc && a.PH >= 30 && a.PW >= 30 &&
+           a.tile == 0;   // an explicit tile (fn_conv_desc.tile_*) asks for the implicit-GEMM kernel
 }
 static int halo_bn(const ConvArgs& a) { return a.NOUT <= 32 ? 32 : (a.NOUT <= 48 || (a.NOUT > 64 && a.NOUT <= 96) ? 32 : 64); }
 
@@ -851,11 +856,8 @@ template <typename T, int BN, int WM, int WN, int KH, int KW> static int launch_
     a.total_tiles = (int)total;
     const size_t smem = halo_smem_bytes(BN, KH, KW);
     auto kern = conv_halo_kernel<T, BN, WM, WN, KH, KW>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static LdsOptIn lds_ok;   // one per instantiation
+    if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), lds_ok, "conv_halo")) return rc;
     hipLaunchKernelGGL(kern, dim3(a.total_tiles), dim3(256), smem, st, a);
     return check_launch("conv_halo");
 }
@@ -900,11 +902,8 @@ static size_t conv_smem_bytes(int BM, int BN, int KTOT, int plain, int norm_chan
 template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, int MODE>
 static int launch_conv_grouped_p(const ConvArgs* dev_args, const int32_t* dev_prefix, int n, int total, size_t smem, hipStream_t st) {
     auto kern = conv_igemm_grouped_kernel<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, MODE>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static LdsOptIn lds_ok;   // one per instantiation
+    if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), lds_ok, "conv_igemm_grouped")) return rc;
     hipLaunchKernelGGL(kern, dim3(total), dim3(256 * KS), smem, st, dev_args, dev_prefix, n);
     return check_launch("conv_igemm_grouped");
 }
@@ -919,11 +918,8 @@ static int launch_conv_p(const ConvArgs& a0, hipStream_t st) {
         return FN_EUNSUPPORTED;
     }
     auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, MODE>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static LdsOptIn lds_ok;   // one per instantiation
+    if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), lds_ok, "conv_igemm")) return rc;
     hipLaunchKernelGGL(kern, dim3(a.total_tiles), dim3(256 * KS), smem, st, a);
     return check_launch("conv_igemm");
 }
@@ -962,7 +958,7 @@ static void choose_conv_tile(int M, int NOUT, int forced, int& bm, int& bn) {
 }
 
 static bool valid_tile(int t) {
-    if (t == 0) return true;
+    if (t == 0 || t == TILE_HALO) return true;
     const int bm = t / 1000, bn = t % 1000;
     return (bm == 128 || bm == 64 || bm == 32) && (bn == 128 || bn == 64 || bn == 32);
 }
@@ -1002,6 +998,10 @@ static int variant_code(int bm, int bn, int ks) { return bm * 1000 + bn + (ks > 
 
 template <typename T> static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     if (halo_eligible(a)) return launch_halo<T>(a, st);
+    if (a.tile == TILE_HALO) {
+        set_error("conv: the halo-tile kernel was requested (tile %d) for a layer it cannot run (needs 3x3, stride 1, channels %% 8 == 0)", a.tile);
+        return FN_EUNSUPPORTED;
+    }
     int bm, bn;
     choose_conv_tile(a.M, a.NOUT, a.tile, bm, bn);
     if (const char* f = getenv("FN_CONV_TILE")) {   // tuning aid: "BMxBN"
@@ -1407,7 +1407,7 @@ static int make_fwd_args(const fn_conv_desc* d, ConvArgs& a) {
                "conv_fwd: x or w exceeds the 1 GiB range of 32-bit buffer offsets");
     a.src_bytes = d->N * d->H * d->W * d->ld_x * 2;
     a.w_bytes = d->Cout * a.KTOT * 2;
-    FN_REQUIRE(valid_tile(d->tile_fwd), "conv_fwd: tile_fwd=%d is not one of {128,64,32}x{128,64,32}", d->tile_fwd);
+    FN_REQUIRE(valid_tile(d->tile_fwd), "conv_fwd: tile_fwd=%d is not one of {128,64,32}x{128,64,32} or 9000000 (halo)", d->tile_fwd);
     a.tile = d->tile_fwd;
     if (d->nrm_stats) {
         FN_REQUIRE(d->nrm_beta && d->Cin <= 512 && d->nrm_count > 0 && d->nrm_eps > 0.f, "conv_fwd: normalise-on-load needs beta, Cin <= 512, count, eps");
@@ -1444,7 +1444,7 @@ static int make_dgrad_args(const fn_conv_desc* d, ConvArgs& a) {
                "conv_dgrad: dy or wt exceeds the 1 GiB range of 32-bit buffer offsets");
     a.src_bytes = d->N * d->OH * d->OW * d->ld_y * 2;
     a.w_bytes = d->Cin * a.KTOT * 2;
-    FN_REQUIRE(valid_tile(d->tile_dgrad), "conv_dgrad: tile_dgrad=%d is not one of {128,64,32}x{128,64,32}", d->tile_dgrad);
+    FN_REQUIRE(valid_tile(d->tile_dgrad), "conv_dgrad: tile_dgrad=%d is not one of {128,64,32}x{128,64,32} or 9000000 (halo)", d->tile_dgrad);
     a.tile = d->tile_dgrad;
     if (d->dy2) {   // sibling sources
         FN_REQUIRE(a.plain && d->w2 && d->Cout2 > 0 && d->Cout2 % 8 == 0 && d->ld_y2 % 8 == 0 && d->ld_y2 >= d->Cout2 && !d->bn_y,
@@ -1640,6 +1640,7 @@ extern "C" int fn_conv2d_variant(const fn_conv_desc* d, int op) {
     if (op < 2) {   // halo-tile kernel: 9000000 + BN (never grouped, never re-tiled)
         ConvArgs ca;
         if ((op == 0 ? make_fwd_args(d, ca) : make_dgrad_args(d, ca)) == FN_OK && halo_eligible(ca)) return 9000000 + halo_bn(ca);
+        if ((op == 0 ? d->tile_fwd : d->tile_dgrad) == TILE_HALO) return FN_EUNSUPPORTED;   // requested, but not a layer the kernel runs
     }
     if (op == 0) {
         choose_conv_tile(d->N * d->OH * d->OW, d->Cout, valid_tile(d->tile_fwd) ? d->tile_fwd : 0, a, b);

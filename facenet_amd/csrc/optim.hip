@@ -11,7 +11,7 @@
 
 namespace fn {
 
-// hyper: [0]=lr [1]=beta1^t [2]=beta2^t [3]=grad_scale ; powers are those AFTER this step's tick
+// hyper: [0]=lr [1]=beta1^t [2]=beta2^t [3]=grad_scale [4]=t (int32 bits) ; powers are those AFTER this step's tick
 template <typename T>
 __global__ __launch_bounds__(256) void adam_keras_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, unsigned short* __restrict__ w_lp, long n_lp, long n, long n_decay,
@@ -43,9 +43,15 @@ __global__ __launch_bounds__(256) void adam_keras_kernel(float* __restrict__ w, 
     }
 }
 
+// Adam's step count is an integer (word 4 of `hyper`); the beta powers are re-derived from it on every tick.  A running
+// product beta1^t in fp32 reaches the denormal floor after ~970 steps and stops changing, so t could not be recovered from it
+// (checkpoints: Adam/iter) -- and Keras computes pow(beta, t) from its integer `iterations` as well.
 __global__ void adam_tick_kernel(float* hyper, float beta1, float beta2) {
-    hyper[1] *= beta1;
-    hyper[2] *= beta2;
+    int* it = reinterpret_cast<int*>(hyper) + 4;
+    const int t = *it + 1;
+    *it = t;
+    hyper[1] = (float)pow((double)beta1, (double)t);
+    hyper[2] = (float)pow((double)beta2, (double)t);
 }
 
 // one workgroup column per layer (blockIdx.y); table row = {w_off, cout, ktot, taps, cin, bn_off, fold_bias_off, 0}.

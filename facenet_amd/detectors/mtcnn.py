@@ -471,9 +471,13 @@ def weights_from_lists(lists: dict) -> dict:
 
 
 def load_weights(path) -> dict:
+    """Named variables from an ``.npz`` (numeric arrays only, ``allow_pickle=False``: nothing in the file is executed).
+    The PyPI package's own ``mtcnn_weights.npy`` is a PICKLED dict of lists; loading a pickle runs code from the file, so
+    it is not accepted here -- convert it once, offline and explicitly, with ``tools/convert_mtcnn_weights.py`` (restricted
+    unpickler: ndarray / list / dict only) and point ``mtcnn.weights_file`` at the resulting ``.npz``."""
     path = str(path)
-    if path.endswith(".npz"):
-        with np.load(path) as z:
-            return {k: np.asarray(z[k]) for k in z.files}
-    # the package's own format: a pickled dict of lists -- only ever a file the user supplies
-    return weights_from_lists(np.load(path, allow_pickle=True).tolist())
+    if not path.endswith(".npz"):
+        raise ValueError(f"MTCNN weights must be an .npz of named variables, got {path!r}; convert the package's pickled "
+                         f"mtcnn_weights.npy with tools/convert_mtcnn_weights.py")
+    with np.load(path, allow_pickle=False) as z:
+        return {k: np.asarray(z[k]) for k in z.files}

@@ -212,6 +212,11 @@ def group_convs(ops: List[Op], net: Network) -> List[Op]:
     return out
 
 
+def adam_beta_powers(t: int, beta1: float, beta2: float) -> Tuple[float, float]:
+    """(beta1^t, beta2^t) as fn_adam_tick derives them from the integer step count: pow in double, rounded to fp32 once."""
+    return float(np.float32(np.float64(beta1) ** t)), float(np.float32(np.float64(beta2) ** t))
+
+
 def _streams_for(net: Network, n_streams: int) -> StreamSet:
     ss = getattr(net, "_stream_set", None)
     if ss is None or len(ss.side) < n_streams - 1:
@@ -245,8 +250,9 @@ class Trainer:
         self.G = net.G
         self.M = torch.zeros_like(self.G)
         self.V = torch.zeros_like(self.G)
-        # hyper = {lr, beta1^t, beta2^t, grad_scale}; lives on device so HIP-graph replays see LR changes
-        self.hyper = torch.tensor([lr, 1.0, 1.0, 1.0 / world_size], dtype=torch.float32, device=dev)
+        # hyper = {lr, beta1^t, beta2^t, grad_scale, t (int32 bits), 3 spare words}; lives on device so HIP-graph replays see
+        # LR changes and advance Adam's step count themselves (fn_adam_tick)
+        self.hyper = torch.tensor([lr, 1.0, 1.0, 1.0 / world_size, 0.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         if world_size > 1:
             # MirroredStrategy creates every replica from the SAME variables (apps/train_softmax_tf2_gpus.py:49-67): rank 0's
@@ -319,6 +325,7 @@ class Trainer:
         self.tiles = autotune_convs(self.plan.fwd + self.loss_ops + self.plan.bwd, net)
         self._build_segments()
         self._graph = None
+        self._exchange_events: Optional[dict] = None     # set by exchange_profile() around a step
 
     def _op(self, lst, name, fn, *args, keep=(), r=(), w=()):
         lst.append(Op(name, fn, args, tuple(keep), tuple(r), tuple(w)))
@@ -410,6 +417,7 @@ class Trainer:
                     launch(i)
             return
         cur = torch.cuda.current_stream(self.net.device)
+        prof = self._exchange_events
         for i, (sched, rng) in enumerate(self.segments[:-1]):
             if sched is not None:
                 launch(i)
@@ -417,9 +425,46 @@ class Trainer:
             ev.record(cur)
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
+                if prof is not None:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(self.comm_stream)
                 self._allreduce(*rng)
+                if prof is not None:
+                    b.record(self.comm_stream)
+                    prof["buckets"].append((rng, a, b))
+        if prof is not None:           # the compute stream has issued the whole backward: what is still exchanging now is exposed
+            prof["bwd_end"] = torch.cuda.Event(enable_timing=True)
+            prof["bwd_end"].record(cur)
         cur.wait_stream(self.comm_stream)
         launch(len(self.segments) - 1)
+
+    def exchange_profile(self, steps: int = 3) -> dict:
+        """Data-parallel runs: per-bucket all-reduce durations (HIP events on the communication stream) and the fraction of
+        the exchange that ran while the compute stream was still inside backward (hidden) -- the rest delays the optimiser.
+        Runs `steps` ordinary steps (they count as training steps) and reports their mean."""
+        if self.world <= 1:
+            return {"buckets": [], "allreduce_ms": 0.0, "overlapped_frac": None}
+        per_bucket, hidden, total = None, 0.0, 0.0
+        for _ in range(steps):
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record(torch.cuda.current_stream(self.net.device))
+            self._exchange_events = {"buckets": []}
+            try:
+                self.step()
+            finally:
+                prof, self._exchange_events = self._exchange_events, None
+            torch.cuda.synchronize(self.net.device)
+            t_end = t0.elapsed_time(prof["bwd_end"])
+            ms = []
+            for (rng, a, b) in prof["buckets"]:
+                ta, tb = t0.elapsed_time(a), t0.elapsed_time(b)
+                ms.append(tb - ta)
+                total += tb - ta
+                hidden += max(0.0, min(tb, t_end) - min(ta, t_end))
+            per_bucket = ms if per_bucket is None else [x + y for x, y in zip(per_bucket, ms)]
+        return {"buckets": [{"elements": int(hi - lo), "mbytes": round(4e-6 * (hi - lo), 2), "allreduce_ms": round(m / steps, 4)}
+                            for (_, lo, hi), m in zip(self.buckets, per_bucket)],
+                "allreduce_ms": round(total / steps, 4), "overlapped_frac": round(hidden / total, 4) if total > 0 else None}
 
     def step_eager(self):
         """zero -> forward -> loss -> backward (+ bucketed all-reduce) -> Adam; the loss stays on device."""
@@ -429,13 +474,14 @@ class Trainer:
         """Capture every segment into a HIP graph (multi-stream edges become graph dependencies); with world_size > 1
         the all-reduces are issued between graph launches on the communication stream.
 
-        ROCm 7.0/7.2 note (measured on MI355X): ending a capture whose fork/join pattern spans 3 or more streams
-        segfaults inside hipStreamEndCapture, while 2 streams capture and replay correctly -- schedules wider than 2
-        streams are therefore re-placed on 2 streams for the captured path (eager replay keeps the requested width)."""
-        max_streams = int(os.environ.get("FACENET_CAPTURE_MAX_STREAMS", "2"))     # > 2 only to investigate the note above
-        if self.n_streams > max_streams:
-            self.n_streams = max_streams
-            self._build_segments()
+        Captured schedules span at most 2 streams.  Ending a capture whose fork / join pattern spans 3 or more streams
+        segfaults inside hipStreamEndCapture under torch.cuda.graph on ROCm 7.0/7.2 (MI355X; 2 streams capture and replay
+        correctly, and a single in-order stream replays fastest anyway: DESIGN.md section 5), so a wider trainer is refused
+        here instead of being offered a way to crash a process that has initialised the GPU.  Eager replay
+        (``step_eager``) keeps the requested width."""
+        if self.n_streams > 2:
+            raise ValueError(f"captured schedules span at most 2 streams (got n_streams={self.n_streams}); build the Trainer with "
+                             f"n_streams <= 2 or replay eagerly (step_eager)")
         # The warm-up below is a full training step on whatever the image buffer holds.  Training state is snapshotted and
         # restored around it, so capture() followed by n steps equals n eager steps (Adam's t, the moving statistics and the
         # parameters are untouched; the reference's fit() has no uncounted step either).
@@ -502,12 +548,8 @@ class Trainer:
         for slot, buf in (("m", self.M), ("v", self.V)):
             for key, t in net.export_keras_grads(buf).items():
                 out[keras_names.optimizer_slot_names(table[key])[0 if slot == "m" else 1]] = t.numpy()
-        h = self.hyper.cpu().numpy()
-        # beta1^t -> t (hyper[1] is the running power the fused optimiser reads)
-        it = 0 if h[1] >= 1.0 else int(round(float(np.log(h[1]) / np.log(self.beta1))))
-        out["Adam/iter:0"] = np.asarray(it, dtype=np.int64)
-        out["Adam/learning_rate:0"] = np.asarray(h[0], dtype=np.float32)
-        out["Adam/beta_powers"] = h[1:3].astype(np.float32)
+        out["Adam/iter:0"] = np.asarray(self.iterations, dtype=np.int64)
+        out["Adam/learning_rate:0"] = np.asarray(self.hyper[0].item(), dtype=np.float32)
         out["epoch"] = np.asarray(int(epoch), dtype=np.int64)
         return out
 
@@ -533,8 +575,29 @@ class Trainer:
                     tmp[i] = torch.from_numpy(sd[keras_names.optimizer_slot_names(k)[slot]])
                 buf.copy_(net.flat_from_keras(tmp))
             self.hyper[0:1].fill_(float(sd["Adam/learning_rate:0"]))
-            self.hyper[1:3].copy_(torch.from_numpy(sd["Adam/beta_powers"]))
+            self.iterations = int(sd["Adam/iter:0"])
         return int(sd.get("epoch", 0))
+
+    @property
+    def iterations(self) -> int:
+        """Keras' ``optimizer.iterations``: optimiser steps taken so far (an int32 word on the device, bumped by fn_adam_tick)."""
+        return int(self.hyper.view(torch.int32)[4].item())
+
+    @iterations.setter
+    def iterations(self, t: int):
+        """Sets the step count and the beta powers that belong to it (what the NEXT tick will overwrite with t + 1)."""
+        if t < 0:
+            raise ValueError(f"Adam iteration count must be >= 0, got {t}")
+        self.hyper.view(torch.int32)[4:5].fill_(int(t))
+        self.hyper[1:3].copy_(torch.tensor(adam_beta_powers(t, self.beta1, self.beta2)))
+
+    def reset_optimizer(self, lr: Optional[float] = None):
+        """Adam as freshly constructed: zero moments, t = 0."""
+        self.M.zero_()
+        self.V.zero_()
+        self.iterations = 0
+        if lr is not None:
+            self.set_learning_rate(lr)
 
     def set_learning_rate(self, lr: float):
         self.hyper[0:1].fill_(float(lr))     # device write: visible to the next graph replay

@@ -80,8 +80,9 @@ typedef struct fn_conv_desc {
      * fn_bn_relu_train_fwd launch of the producing layer; the weight gradient then reads nrm_z like any activation. */
     void* nrm_z;
     /* fwd / dgrad tile variant: 0 = library heuristic, BM*1000+BN with BM, BN in {128, 64, 32} = caller's choice (the host side
-     * times the candidates once per plan: facenet_amd/engine.py autotune).  Results do not depend on the tile beyond the
-     * summation order. */
+     * times the candidates once per plan: facenet_amd/engine.py autotune), 9000000 = the halo-tile kernel (3x3, stride 1,
+     * channels a multiple of 8; FN_EUNSUPPORTED otherwise) also where the heuristic would not pick it.  Results do not depend
+     * on the tile beyond the summation order. */
     int32_t tile_fwd, tile_dgrad;
     /* dgrad of SIBLING 1x1 stride-1 layers that read the same x (inception towers branching off one trunk): dX = y-gradient of
      * this layer times its transposed pack PLUS the same for up to two more layers (dy2/w2, dy3/w3; their Cout and dy row
@@ -269,7 +270,8 @@ int fn_softmax_xent_fwd_bwd(const float* logits, int ld, const int32_t* labels, 
                             int C, float grad_scale, int dtype, void* stream);
 
 /* ---- optimiser: tf.keras.optimizers.Adam(epsilon=0.1) apps/train_softmax.py:92 + Keras L2(5e-4) (:65) ----
- * hyper = device fp32[4] {lr, beta1^t, beta2^t, grad_scale}; the kernel advances beta powers itself (graph replay safe).
+ * hyper = device word[8] {lr, beta1^t, beta2^t, grad_scale, t (int32: Keras' `iterations`), 3 spare}; fn_adam_tick advances t and
+ * re-derives the beta powers from it on the device (graph replay safe; t survives past the fp32 underflow of beta1^t).
  * Elements [0, n_decay) get the coupled L2 term g += 2*l2*w.  w_lp receives the low-precision copy of w[0, n_lp). */
 int fn_adam_keras(float* w, const float* g, float* m, float* v, void* w_lp, long n_lp, long n, long n_decay, float* hyper, float beta1,
                   float beta2, float eps, float l2, int dtype, void* stream);

@@ -5,7 +5,8 @@ SELF-GENERATED, NOT REFERENCE-DERIVED: sMedX/FaceNet ships no fixtures, golden v
 TensorFlow is not installable here, so these vectors pin the ORACLE (against drift) and give the GPU tests committed
 expected outputs; they cannot pin the oracle to the reference ("parity unpinned").
 
-    python oracle/make_golden.py          # rewrites tests/golden/
+    python oracle/make_golden.py                      # rewrites every fixture under tests/golden/
+    python oracle/make_golden.py triplets b90         # only the named sections: c1 image triplets trajectory b90
 Inputs are re-created from seeds by the tests (numpy default_rng / torch.Generator), only outputs are stored.
 """
 import os
@@ -22,9 +23,17 @@ from tests.util_data import c1_images, structured_images, triplet_pool  # noqa: 
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
-def main():
-    os.makedirs(OUT, exist_ok=True)
-    torch.set_num_threads(min(8, torch.get_num_threads()))
+B90_LAYERS = ("conv2d/Conv2d_1a_3x3/kernel", "conv2d/Conv2d_4b_3x3/kernel", "block35/2/up/kernel",
+              "reduction_a/tower_conv1/Conv2d_0b_3x3/kernel", "block17/4/tower_conv1/Conv2d_0b_1x7/kernel", "block17/9/up/kernel",
+              "block8/2/up/kernel", "features/logits/kernel")
+
+
+def b90_batch(step: int) -> np.ndarray:
+    """The 90-image (30 triplets, rows a,p,n) batch of trajectory step `step`: seeded structured images, a fresh batch per step."""
+    return structured_images(90, seed=900 + step)
+
+
+def section_c1():
     # ---- C1: forward embeddings (BASELINE.json configs[0]; SURVEY.md 8d C1) --------------------------------
     x = c1_images()
     emb = {}
@@ -48,16 +57,22 @@ def main():
                 np.savez_compressed(os.path.join(OUT, "c1_taps_128_perturbed.npz"), **taps)
     np.savez_compressed(os.path.join(OUT, "c1_embeddings.npz"), **emb)
 
+
+def section_image():
     # ---- image processing (facenet.py:67-86) ---------------------------------------------------------------
     xi = c1_images(3)
     xi[1] = 77
     ip = {f"mode{m}": fo.image_processing(xi, m).numpy()[:, ::16, ::16, :].astype(np.float32) for m in (0, 1)}
     np.savez_compressed(os.path.join(OUT, "image_processing.npz"), **ip)
 
+
+def section_triplets():
     # ---- triplet selection (build-defined, A13) ------------------------------------------------------------
     embp, labels = triplet_pool()
-    dist = fo.squared_distance_matrix(embp)
-    sel = {"dist_checksum": np.array([dist.sum(dtype=np.float64), (dist ** 2).sum(dtype=np.float64)])}
+    dist = fo.squared_distance_matrix(embp)          # device summation order: bit-identical to fn_pairwise_sqdist
+    import hashlib
+    sel = {"dist_checksum": np.array([dist.sum(dtype=np.float64), (dist ** 2).sum(dtype=np.float64)]),
+           "dist_sha1": np.frombuffer(hashlib.sha1(np.ascontiguousarray(dist).tobytes()).digest(), dtype=np.uint8)}
     for seed in (0, 7):
         for semi in (0, 1):
             sel[f"triplets_seed{seed}_semi{semi}"] = fo.select_triplets(dist, labels, 0.2, 30, seed, semi_hard=bool(semi))
@@ -65,6 +80,8 @@ def main():
     sel["pairwise_metric0_triu_first40"] = sims.astype(np.float32)
     np.savez_compressed(os.path.join(OUT, "triplets.npz"), **sel)
 
+
+def section_trajectory():
     # ---- 3-step training trajectories (loss + parameter checksums) -----------------------------------------
     traj = {}
     for kind in ("triplet", "softmax"):
@@ -87,7 +104,41 @@ def main():
         traj[f"{kind}_losses"] = np.array(losses)
         traj[f"{kind}_param_sums"] = np.array(sums)
     np.savez_compressed(os.path.join(OUT, "train_trajectory.npz"), **traj)
-    print("golden fixtures written to", OUT)
+
+
+def section_b90():
+    """Training fidelity at the REAL configuration (BASELINE.json configs[1]): 5 triplet steps at batch 90 (30 triplets), E = 128,
+    Keras Adam(eps 0.1) lr 0.05, L2 5e-4, fp32 oracle.  Per step: data loss, total loss, and the L2 norm of the DATA gradient
+    (without the coupled L2 term, which the device adds inside the optimiser) of eight kernels spread over the depth."""
+    params, trainable, regularized = fo.build_params(128, seed=0)
+    opt = fo.AdamKeras(trainable, params, lr=0.05)
+    losses, norms, emb_norm = [], [], []
+    for step in range(5):
+        data, total, grads, stats, emb = fo.train_step_grads(params, trainable, regularized, b90_batch(step), "triplet", alpha=0.2)
+        norms.append([(grads[k] - 2.0 * fo.L2_WEIGHT * params[k]).double().norm().item() for k in B90_LAYERS])
+        emb_norm.append(emb.double().norm(dim=1).mean().item())
+        opt.step(params, grads)
+        for k, v in stats.items():
+            params[k].copy_(v)
+        losses.append([data, total])
+        print(f"b90 step {step}: loss {data:.5f} total {total:.5f} |g| {norms[-1]}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "train_trajectory_b90.npz"), losses=np.array(losses), grad_norms=np.array(norms),
+                        emb_norm=np.array(emb_norm), layers=np.array(B90_LAYERS))
+
+
+SECTIONS = {"c1": section_c1, "image": section_image, "triplets": section_triplets, "trajectory": section_trajectory, "b90": section_b90}
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    want = sys.argv[1:] or list(SECTIONS)
+    for name in want:
+        if name not in SECTIONS:
+            raise SystemExit(f"unknown section {name!r}; choose from {list(SECTIONS)}")
+    for name in want:
+        SECTIONS[name]()
+    print("golden fixtures written to", OUT, want)
 
 
 if __name__ == "__main__":

@@ -5,8 +5,6 @@ import pytest
 
 # plans in the tests use the library tile heuristic (deterministic, fast); the tuner has its own test
 os.environ.setdefault("FACENET_AUTOTUNE", "0")
-# the halo-tile convolution is production-limited to <= 64 source channels (where it wins); the kernel tests cover it wider
-os.environ.setdefault("FN_CONV_HALO_MAXC", "512")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

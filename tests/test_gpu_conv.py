@@ -34,6 +34,15 @@ CASES = [
     (2, 35, 35, 192, 80, 3, 3, 1, 0, 0),   # Cout=80 (three 32-wide column tiles, the last half empty), six input slices
 ]
 HALO_CASES = CASES[-4:]
+HALO = 9000000      # fn_conv_desc.tile_*: ask for the halo-tile kernel (production picks it only for <= 64 source channels, where it wins)
+
+
+def _halo(d, case):
+    """The halo cases run on conv_halo_kernel whatever the production heuristic would choose (per-descriptor request: the model,
+    golden and training tests dispatch exactly like bench.py and users do)."""
+    if case in HALO_CASES:
+        d.tile_fwd = d.tile_dgrad = HALO
+    return d
 
 
 def test_halo_cases_dispatch_to_the_halo_kernel(lib):
@@ -43,12 +52,23 @@ def test_halo_cases_dispatch_to_the_halo_kernel(lib):
         d = conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, _lib.FN_BF16)
         t = torch.zeros(16, device="cuda")
         d.x = d.w = d.y = d.dx = ptr(t)
+        prod = Cin <= 64, Cout <= 64       # the production heuristic: at most 64 SOURCE channels (forward: Cin, data gradient: Cout)
+        assert (lib.fn_conv2d_variant(C.byref(d), 0) >= 9000000) == prod[0] and (lib.fn_conv2d_variant(C.byref(d), 1) >= 9000000) == prod[1]
+        d.tile_fwd = d.tile_dgrad = HALO
         assert lib.fn_conv2d_variant(C.byref(d), 0) >= 9000000 and lib.fn_conv2d_variant(C.byref(d), 1) >= 9000000
         d.tile_fwd = d.tile_dgrad = 64064
         assert lib.fn_conv2d_variant(C.byref(d), 0) % 1000000 == 64064 and lib.fn_conv2d_variant(C.byref(d), 1) % 1000000 == 64064   # (+ 2e6: in-launch split-K)
     d = conv_desc(2, 17, 17, 32, 32, 3, 3, 1, 1, 1, _lib.FN_BF16)          # small map: implicit GEMM
     d.x = d.w = d.y = d.dx = ptr(torch.zeros(16, device="cuda"))
     assert lib.fn_conv2d_variant(C.byref(d), 0) < 9000000
+    d.tile_fwd = HALO                                                       # an explicit request is honoured on any map size ...
+    assert lib.fn_conv2d_variant(C.byref(d), 0) >= 9000000
+    d = conv_desc(2, 17, 17, 64, 64, 1, 1, 1, 0, 0, _lib.FN_BF16)           # ... but not for a layer the kernel cannot run
+    d.x = d.w = d.y = d.dx = ptr(torch.zeros(16, device="cuda"))
+    d.tile_fwd = HALO
+    assert lib.fn_conv2d_variant(C.byref(d), 0) < 0
+    with pytest.raises(_lib.FacenetHipError):
+        _lib.check(lib.fn_conv2d_fwd(C.byref(d), stream()))
 
 
 def _mk(shape, dt, scale=1.0, seed=0):
@@ -62,7 +82,7 @@ def test_conv_fwd(lib, case, dt):
     N, H, W, Cin, Cout, kh, kw, s, ph, pw = case
     x = _mk((N, H, W, Cin), dt, seed=1)
     w = _mk((Cout, kh, kw, Cin), dt, 0.1, seed=2)
-    d = conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt)
+    d = _halo(conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt), case)
     y = torch.full((N, d.OH, d.OW, Cout), 7.0, dtype=lp_dtype(dt), device="cuda")
     reps = 4
     stats_r = torch.zeros(reps, 2 * Cout, dtype=torch.float32, device="cuda")
@@ -113,7 +133,7 @@ def test_conv_fwd_epilogues_and_slices(lib, dt):
 @pytest.mark.parametrize("case", CASES[1:])
 def test_conv_dgrad(lib, case, dt):
     N, H, W, Cin, Cout, kh, kw, s, ph, pw = case
-    d = conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt)
+    d = _halo(conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt), case)
     dy = _mk((N, d.OH, d.OW, Cout), dt, seed=11)
     w = _mk((Cout, kh, kw, Cin), dt, 0.1, seed=12)
     wt = torch.zeros_like(w).view(-1)
@@ -216,6 +236,9 @@ def test_dgrad_fused_bn_backward_reduction(lib, dt, H):
     reduce kernel; the apply kernel then consumes the replicated accumulators."""
     N, W, Cin, Cout = 3, H, 64, 96
     d = conv_desc(N, H, W, Cin, Cout, 3, 3, 1, 1, 1, dt)
+    if H == 37:
+        d.tile_dgrad = HALO          # 96 source channels: production would take the implicit-GEMM kernel
+        assert lib.fn_conv2d_variant(C.byref(d), 1) >= 9000000
     M = N * H * W
     dy = _mk((N, H, W, Cout), dt, seed=51)
     w = _mk((Cout, 3, 3, Cin), dt, 0.1, seed=52)

@@ -37,7 +37,7 @@ def _rank(rank, world, port, q, use_graph):
         if use_graph:
             tr.capture()                       # one eager warm-up step + capture: restart from the same state
             net.load_keras_params(params)
-            tr.M.zero_(); tr.V.zero_(); tr.hyper.copy_(torch.tensor([0.01, 1.0, 1.0, 1.0 / world]))
+            tr.reset_optimizer(lr=0.01)
         tr.step()
         torch.cuda.synchronize()
         q.put((rank, net.P.cpu().numpy(), tr.G.cpu().numpy(), tr.loss_value()))

@@ -177,7 +177,7 @@ def test_scheduled_multistream_step_matches_serial_replay():
         else:
             tr.capture()                     # capture() runs one eager step first: restart from the same state
             net.load_keras_params(params)
-            tr.M.zero_(); tr.V.zero_(); tr.hyper.copy_(torch.tensor([0.01, 1.0, 1.0, 1.0]))
+            tr.reset_optimizer(lr=0.01)
             tr.step()
         torch.cuda.synchronize()
         results.append((tr.loss_value(), tr.emb.clone(), tr.G.clone(), net.P.clone()))

@@ -86,7 +86,7 @@ def test_capture_leaves_training_state_untouched():
     tr.step()
     torch.cuda.synchronize()
     h = tr.hyper.cpu().numpy()
-    assert abs(h[1] - 0.9) < 1e-6 and abs(h[2] - 0.999) < 1e-6          # exactly one optimiser step: t = 1
+    assert abs(h[1] - 0.9) < 1e-6 and abs(h[2] - 0.999) < 1e-6 and tr.iterations == 1   # exactly one optimiser step: t = 1
     assert float((net.P - before[0]).abs().max()) > 0
 
 
@@ -136,13 +136,27 @@ def test_checkpoint_round_trip_in_keras_naming(tmp_path):
         ga, gb = net.export_keras_grads(buf), net2.export_keras_grads(buf2)
         for k in ga:
             assert torch.equal(ga[k], gb[k]), k
-    assert torch.equal(tr.hyper[:3], tr2.hyper[:3])
+    assert torch.equal(tr.hyper[:3], tr2.hyper[:3]) and tr2.iterations == tr.iterations == 2
     assert torch.equal(net.W_train, net2.W_train)              # packs were refreshed from the restored masters
     # the model alone restores from the same file (InceptionResnetV1.load_weights path: names, not positions)
     net3 = Network(embedding_size=128, device="cuda:0", nrof_classes=11, seed=5)
     with np.load(path) as z:
         net3.load_keras_params({k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("Adam/") and k != "epoch"})
     assert torch.equal(net3.P, net.P)
+    # Adam's t is an integer of its own: a checkpoint written after more steps than beta1^t survives in fp32 (~970) keeps it
+    tr.iterations = 1100
+    tr.step()
+    torch.cuda.synchronize()
+    assert tr.iterations == 1101 and float(tr.hyper[1]) == 0.0 and abs(float(tr.hyper[2]) - 0.999 ** 1101) < 1e-6
+    late = tmp_path / "late.npz"
+    tr.save_checkpoint(late, epoch=1)
+    with np.load(late) as z:
+        assert int(z["Adam/iter:0"]) == 1101
+    tr2.load_checkpoint(late)
+    assert tr2.iterations == 1101 and torch.equal(tr.hyper.view(torch.int32)[:5], tr2.hyper.view(torch.int32)[:5])
+    tr.step(); tr2.step()
+    torch.cuda.synchronize()
+    assert tr2.iterations == 1102 and torch.equal(tr.hyper.view(torch.int32)[:5], tr2.hyper.view(torch.int32)[:5])
 
 
 def test_bn_folded_export_matches_tfutils_formula():

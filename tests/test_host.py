@@ -42,6 +42,14 @@ def test_config_mirror():
     assert c.a.b == 1 and c.x == 2
     assert not c.missing and not c.missing.deeper           # config.py:85-89: missing attribute -> empty falsy Config
     assert c.as_dict == {"a": {"b": 1}, "x": 2} and c.exists("x") and not c.exists("y")
+    assert repr(c) == "a: \n   b: 1\nx: 2\n"                # config.py:71-83: nested sections three spaces deeper
+    assert dict(c.items())["x"] == 2 and isinstance(dict(c.items())["a"], Config)
+    c.a.z = {"k": 3}                                         # assignment wraps dicts like the constructor (config.py:64-68)
+    assert c.a.z.k == 3 and c.as_dict["a"] == {"b": 1, "z": {"k": 3}}
+    import copy
+    d = copy.deepcopy(c)
+    d.a.b = 9
+    assert c.a.b == 1 and d.a.b == 9 and not Config() and not Config({})
     cfg = load_config()
     assert cfg.batch_size == 100 and cfg.image.size == 160 and cfg.image.normalization == 0   # apps/configs/config.yaml:7,11,15
     assert cfg.train.epoch.size == 1000 and cfg.train.epoch.nrof_epochs == 300                # train_softmax.yaml:37 ; config.py:181-182
@@ -131,3 +139,22 @@ def test_keras_variable_names_and_order():
         keras_names.from_keras({k: v for k, v in keras.items() if "block17_3" not in k}, net.layers)
     assert keras_names.optimizer_slot_names(names[0]) == ("Adam/inception_resnet_v1/conv2d/Conv2d_1a_3x3/kernel/m:0",
                                                           "Adam/inception_resnet_v1/conv2d/Conv2d_1a_3x3/kernel/v:0")
+
+
+def test_adam_iteration_count_survives_beta_power_underflow():
+    """Advisor finding (round 2): Adam's t must be an integer of its own.  The fp32 running product beta1^t stops changing at the
+    denormal floor (~970 steps at beta1 = 0.9), so t = log(power)/log(beta1) maps every later step to the same value; the
+    powers are instead derived FROM t (host mirror of fn_adam_tick: pow in double, one rounding to fp32)."""
+    import numpy as np
+    from facenet_amd.train import adam_beta_powers
+    run = np.float32(1.0)
+    for _ in range(1100):
+        run = np.float32(run * np.float32(0.9))
+    recovered = 0 if run == 0 else int(round(float(np.log(run) / np.log(0.9))))
+    assert recovered != 1100                                   # the defect: the product no longer identifies t
+    b1, b2 = adam_beta_powers(1100, 0.9, 0.999)
+    assert b1 == 0.0 and abs(b2 - 0.999 ** 1100) < 1e-7        # 0.9^1100 = 4.6e-51 underflows to +0 like Keras' fp32 pow
+    assert adam_beta_powers(0, 0.9, 0.999) == (1.0, 1.0)
+    assert adam_beta_powers(1, 0.9, 0.999) == (float(np.float32(0.9)), float(np.float32(0.999)))
+    for t in (10, 500, 969, 980, 1000):                        # distinct t stay distinct through beta2^t long after beta1^t is gone
+        assert adam_beta_powers(t, 0.9, 0.999)[1] > adam_beta_powers(t + 1, 0.9, 0.999)[1]

@@ -106,3 +106,32 @@ def test_face_detector_mirror():
         FaceDetector(detector="other")
     with pytest.raises(NotImplementedError):
         FaceDetector(detector="frcnnv3")
+
+
+def test_weight_files_are_never_unpickled_by_the_product_path(tmp_path):
+    """Advisor finding (round 2): `mtcnn.weights_file` reaches load_weights from the extract_faces app; only `.npz` with
+    allow_pickle=False is accepted there.  The package's pickled mtcnn_weights.npy goes through the offline converter, whose
+    restricted unpickler rebuilds arrays / lists / dicts and refuses every other global."""
+    import os
+    import subprocess
+    import sys
+    from facenet_amd.detectors import mtcnn as gm
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "convert_mtcnn_weights.py")
+    w = mo.random_weights(seed=1)
+    lists = {net: [w[k] for k, _ in mo.variable_shapes(net)] for net in ("pnet", "rnet", "onet")}
+    np.save(tmp_path / "w.npy", lists, allow_pickle=True)
+    with pytest.raises(ValueError):
+        gm.load_weights(tmp_path / "w.npy")                       # the product path refuses the pickle outright
+    assert subprocess.run([sys.executable, tool, str(tmp_path / "w.npy"), str(tmp_path / "w.npz")]).returncode != 0   # no opt-in
+    subprocess.check_call([sys.executable, tool, "--i-trust-this-file", str(tmp_path / "w.npy"), str(tmp_path / "w.npz")])
+    back = gm.load_weights(tmp_path / "w.npz")
+    assert set(back) == set(w) and all(np.array_equal(back[k], w[k]) for k in w)
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("touch " + str(tmp_path / "pwned"),))
+    np.save(tmp_path / "evil.npy", {"pnet": [Evil()], "rnet": [], "onet": []}, allow_pickle=True)
+    r = subprocess.run([sys.executable, tool, "--i-trust-this-file", str(tmp_path / "evil.npy"), str(tmp_path / "evil.npz")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "refusing to load global" in r.stderr and not (tmp_path / "pwned").exists()

@@ -68,7 +68,11 @@ def test_golden_image_processing_and_triplets():
     t = np.load(os.path.join(GOLD, "triplets.npz"))
     emb, labels = triplet_pool()
     dist = fo.squared_distance_matrix(emb)
-    assert np.allclose([dist.sum(dtype=np.float64), (dist ** 2).sum(dtype=np.float64)], t["dist_checksum"], rtol=1e-6)
+    assert np.allclose([dist.sum(dtype=np.float64), (dist ** 2).sum(dtype=np.float64)], t["dist_checksum"], rtol=1e-12)
+    import hashlib
+    assert np.array_equal(np.frombuffer(hashlib.sha1(np.ascontiguousarray(dist).tobytes()).digest(), dtype=np.uint8), t["dist_sha1"])
+    e64 = emb.astype(np.float64)                                       # device-order fp32 matrix vs the definition in float64
+    assert np.abs(dist - ((e64[:, None] - e64[None]) ** 2).sum(-1)).max() < 1e-6 and np.array_equal(dist, dist.T)
     for seed in (0, 7):
         for semi in (0, 1):
             sel = fo.select_triplets(dist, labels, 0.2, 30, seed, semi_hard=bool(semi))
@@ -164,3 +168,23 @@ def test_hash_stream_is_fixed():
     vals = [fo.hash_u32(1, 2, 3), fo.hash_u32(0, 0, 1), fo.hash_u32(123, 269, 2)]
     assert all(0 <= v < 2 ** 32 for v in vals) and len(set(vals)) == 3
     assert vals == [fo.hash_u32(1, 2, 3), fo.hash_u32(0, 0, 1), fo.hash_u32(123, 269, 2)]
+
+
+def test_fma32_is_the_correctly_rounded_fused_multiply_add():
+    """oracle._fma32 (what the device-order distance matrix is built from) against exact rational arithmetic, including a
+    constructed double-rounding case: a*b + c whose float64 sum lands exactly on an fp32 midpoint."""
+    from fractions import Fraction
+    rng = np.random.default_rng(0)
+    a, b, c = (rng.normal(size=3000).astype(np.float32) for _ in range(3))
+    # a = 1 + 2^-12, b = 1 + 2^-12 : a*b = 1 + 2^-11 + 2^-24 (exact); c = 2^-60 pushes the sum just above the fp32 midpoint
+    # 1 + 2^-11 + 2^-24 of (1 + 2^-11, 1 + 2^-11 + 2^-23); float64 drops c -> naive double rounding ties to even (down)
+    a[0] = b[0] = np.float32(1 + 2.0 ** -12)
+    c[0] = np.float32(2.0 ** -60)
+    r = fo._fma32(a, b, c)
+    for i in range(len(a)):
+        exact = Fraction(float(a[i])) * Fraction(float(b[i])) + Fraction(float(c[i]))
+        v = np.float32(r[i])
+        for nb in (np.nextafter(v, np.float32(-np.inf)), np.nextafter(v, np.float32(np.inf))):
+            assert abs(Fraction(float(v)) - exact) <= abs(Fraction(float(nb)) - exact), i
+    assert r[0] == np.float32(1 + 2.0 ** -11 + 2.0 ** -23)            # rounded UP: the fused result, not the double-rounded one
+    assert np.float32(np.float64(a[0]) * np.float64(b[0]) + np.float64(c[0])) != r[0]

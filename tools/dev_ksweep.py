@@ -40,7 +40,7 @@ for N in (90, 180):
     bench(N, 17, 17, 32, 32, 3, 3, 1, 1, 1)
 
 print("--- floor: tiny kernels in a graph")
-hyper = torch.tensor([0.01, 1.0, 1.0, 1.0], device='cuda')
+hyper = torch.tensor([0.01, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0], device='cuda')
 def floor(fn, reps=40):
     g = torch.cuda.CUDAGraph()
     fn(torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
