@@ -59,7 +59,8 @@ _SIGNATURES = {
     "fn_conv2d_group_build": [C.POINTER(ConvDesc), _i, _i, _i, _p, _p, _p],
     "fn_conv2d_grouped": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     "fn_conv2d_wgrad_arg_bytes": [],
-    "fn_conv2d_wgrad_group_build": [C.POINTER(ConvDesc), _i, _i, _p, _p],
+    "fn_conv2d_wgrad_group_build": [C.POINTER(ConvDesc), _i, _i, _p, _p, _p, _p],
+    "fn_conv2d_wgrad_reduce": [_p, _i, _p],
     "fn_conv2d_wgrad_grouped": [_p, _p, _i, _i, _i, _i, _p],
     "fn_image_normalize": [_p, _p, _p, _i, _i, _i, _i, _p],
     "fn_image_normalize_f32": [_p, _p, _p, _i, _i, _i, _i, _p],

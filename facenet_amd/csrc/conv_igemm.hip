@@ -1074,6 +1074,12 @@ struct WgradArgs {
     const float* nrm_beta;
     int nrm_sq_off, nrm_replicas, nrm_rep_stride, nrm_count;
     float nrm_eps;
+    // Grouped launches are DETERMINISTIC and atomic-free: a layer with one split stores its tiles straight into dw; a layer with
+    // several splits stores split z into slab z of `ws` ([splits][Cout*KTOT] fp32) and wgrad_reduce_kernel adds the slabs in
+    // order.  (Global float atomics run at ~1.3 TB/s at the memory side, plain stores at ~6 TB/s, and the order of atomic
+    // adds -- hence the rounding of dW -- changed from run to run.)  mode 0: legacy single launch, atomic accumulation into dw.
+    float* ws;
+    int store;   // 1: plain stores (dw or ws slab), 0: atomicAdd into dw
 };
 
 // k-step pixel permutation shared by both operands: tile row of MFMA k index (g = lane>>4, h = half, q)
@@ -1262,6 +1268,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bx
     }
 
     // C layout: col = lane&15 (kcol), row = (lane>>4)*4 + r (cout)
+    float* const dst = a.ws ? a.ws + (long)bz * a.Cout * a.KTOT : a.dw;
 #pragma unroll
     for (int i = 0; i < MREP; ++i)
 #pragma unroll
@@ -1270,9 +1277,26 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bx
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = c0 + wm * TM + i * 16 + g * 4 + r;
-                if (co < a.Cout && kc < a.KTOT) unsafeAtomicAdd(&a.dw[(long)co * a.KTOT + kc], acc[i][j][r]);
+                if (co < a.Cout && kc < a.KTOT) {
+                    if (a.store) dst[(long)co * a.KTOT + kc] = acc[i][j][r];
+                    else unsafeAtomicAdd(&a.dw[(long)co * a.KTOT + kc], acc[i][j][r]);
+                }
             }
         }
+}
+
+// Second stage of the grouped weight gradients: dw = slab 0 + slab 1 + ... in that order (blockIdx.y = layer).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs* __restrict__ args) {
+    const WgradArgs& a = args[blockIdx.y];
+    if (a.ws == nullptr) return;
+    const long n4 = (long)a.Cout * a.KTOT / 4;          // layer sizes are multiples of 8
+    const f32x4* ws = reinterpret_cast<const f32x4*>(a.ws);
+    f32x4* dw = reinterpret_cast<f32x4*>(a.dw);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 s = ws[i];
+        for (int z = 1; z < a.splits; ++z) s += ws[(long)z * n4 + i];
+        dw[i] = s;
+    }
 }
 
 template <typename T, int BMW, int BNW, bool NORM>
@@ -1581,8 +1605,10 @@ extern "C" int fn_conv2d_wgrad_arg_bytes(void) { return (int)sizeof(WgradArgs); 
 
 // Host-side planning: fills host_args[n * fn_conv2d_wgrad_arg_bytes()] and host_prefix[n+1] for n descriptors that all
 // dispatch to `variant` (= fn_conv2d_variant(desc, 2)); returns the total number of workgroups (or a negative status).
-extern "C" int fn_conv2d_wgrad_group_build(const fn_conv_desc* descs, int n, int variant, void* host_args, int32_t* host_prefix) {
-    FN_REQUIRE(descs && host_args && host_prefix && n > 0, "wgrad_group_build: bad arguments");
+extern "C" int fn_conv2d_wgrad_group_build(const fn_conv_desc* descs, int n, int variant, void* host_args, int32_t* host_prefix, float* ws,
+                                           int64_t* ws_elems) {
+    FN_REQUIRE(descs && host_args && host_prefix && ws_elems && n > 0, "wgrad_group_build: bad arguments");
+    long ws_used = 0;
     const bool norm = variant >= 1000000;
     variant %= 1000000;
     const int bmw = variant / 1000, bnw = variant % 1000;
@@ -1597,13 +1623,27 @@ extern "C" int fn_conv2d_wgrad_group_build(const fn_conv_desc* descs, int n, int
         FN_REQUIRE(descs[i].dtype == descs[0].dtype, "wgrad_group_build: mixed dtypes");
         FN_REQUIRE((a.nrm_stats != nullptr) == norm, "wgrad_group_build: descriptor %d: normalise-on-load members need a group of their own (variant + 1000000)", i);
         const int splits = plan_wgrad(a, descs[i].splits, bmw, bnw, true);
+        FN_REQUIRE(((long)a.Cout * a.KTOT) % 4 == 0, "wgrad_group_build: descriptor %d: Cout*K must be a multiple of 4", i);
+        a.store = 1;
+        a.ws = nullptr;
+        if (splits > 1) {            // slabs of this layer: [splits][Cout*KTOT]; ws == NULL on the sizing call
+            a.ws = ws ? ws + ws_used : reinterpret_cast<float*>(16);
+            ws_used += (long)splits * a.Cout * a.KTOT;
+        }
         host_prefix[i] = (int32_t)total;
         total += (long)a.gx * a.gy * splits;
         out[i] = a;
     }
     FN_REQUIRE(total < (1L << 30), "wgrad_group_build: too many workgroups");
     host_prefix[n] = (int32_t)total;
+    *ws_elems = ws_used;
     return (int)total;
+}
+
+extern "C" int fn_conv2d_wgrad_reduce(const void* dev_args, int n, void* stream) {
+    FN_REQUIRE(dev_args && n > 0 && n < 65536, "wgrad_reduce: bad arguments");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(48, n), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const WgradArgs*>(dev_args));
+    return check_launch("wgrad_reduce");
 }
 
 template <typename T> static int launch_wgrad_grouped(const void* args, const int32_t* prefix, int n, int total, int variant, hipStream_t st) {

@@ -66,7 +66,13 @@ def group_wgrads(ops: List[Op], net: Network) -> List[Op]:
         descs = (_lib.ConvDesc * n)(*[m.keep[0] for m in members])
         host_args = (C.c_uint8 * (nbytes * n))()
         host_prefix = (C.c_int32 * (n + 1))()
-        total = lib.fn_conv2d_wgrad_group_build(descs, n, variant, host_args, host_prefix)
+        ws_elems = C.c_int64(0)
+        total = lib.fn_conv2d_wgrad_group_build(descs, n, variant, host_args, host_prefix, None, C.byref(ws_elems))   # sizing call
+        if total < 0:
+            _lib.check(total, "wgrad_group_build")
+        # split layers write one fp32 slab per pixel split, summed in order by fn_conv2d_wgrad_reduce: no atomics, same bits every run
+        ws = torch.empty(max(1, ws_elems.value), dtype=torch.float32, device=net.device)
+        total = lib.fn_conv2d_wgrad_group_build(descs, n, variant, host_args, host_prefix, _ptr(ws), C.byref(ws_elems))
         if total < 0:
             _lib.check(total, "wgrad_group_build")
         dev_args = torch.frombuffer(bytearray(host_args), dtype=torch.uint8).to(net.device)
@@ -77,8 +83,11 @@ def group_wgrads(ops: List[Op], net: Network) -> List[Op]:
             writes.extend(m.writes)
         out.append(Op(f"conv_wgrad_grouped:{variant % 1000000 // 1000}x{variant % 1000}" + (":norm" if variant >= 1000000 else ""),
                       lib.fn_conv2d_wgrad_grouped,
-                      (_ptr(dev_args), _ptr(dev_prefix), n, total, variant, dt), keep=(descs, dev_args, dev_prefix, members),
-                      reads=tuple(reads), writes=tuple(writes)))
+                      (_ptr(dev_args), _ptr(dev_prefix), n, total, variant, dt), keep=(descs, dev_args, dev_prefix, members, ws),
+                      reads=tuple(reads), writes=tuple(writes) + (region(ws),)))
+        if ws_elems.value > 0:
+            out.append(Op("conv_wgrad_reduce", lib.fn_conv2d_wgrad_reduce, (_ptr(dev_args), n), keep=(dev_args, ws),
+                          reads=(region(ws),), writes=tuple(writes)))
     return out
 
 

@@ -144,8 +144,15 @@ int fn_conv2d_grouped(const void* dev_args, const int32_t* dev_prefix, int n, in
  * on load (nrm_stats) form groups of their own: pass variant + 1000000 to both calls.  Likewise fn_conv2d_grouped takes
  * plain | 2 for a group whose members all normalise on load. */
 int fn_conv2d_wgrad_arg_bytes(void);
-int fn_conv2d_wgrad_group_build(const fn_conv_desc* descs, int n, int variant, void* host_args, int32_t* host_prefix);
+int fn_conv2d_wgrad_group_build(const fn_conv_desc* descs, int n, int variant, void* host_args, int32_t* host_prefix, float* ws,
+                                int64_t* ws_elems);
 int fn_conv2d_wgrad_grouped(const void* dev_args, const int32_t* dev_prefix, int n, int total_blocks, int variant, int dtype, void* stream);
+/* The grouped path is deterministic and free of atomics: a layer that is not split over pixels stores dw directly; a split layer
+ * stores split z into slab z of the workspace `ws` (fp32 [splits][Cout*K] per layer, laid out by group_build) and
+ * fn_conv2d_wgrad_reduce, launched after fn_conv2d_wgrad_grouped with the same dev_args, writes dw = slab 0 + slab 1 + ... in that
+ * order.  Call group_build once with ws = NULL to learn *ws_elems (floats), allocate, and call it again with the pointer.  dw
+ * needs no zeroing on this path.  (fn_conv2d_wgrad, the single-layer launch, still accumulates atomically into a zeroed dw.) */
+int fn_conv2d_wgrad_reduce(const void* dev_args, int n, void* stream);
 /* tile variant the descriptor dispatches to (op 0 fwd, 1 dgrad, 2 wgrad): BM*1000+BN; measurement aid only */
 int fn_conv2d_variant(const fn_conv_desc* d, int op);
 

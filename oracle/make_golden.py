@@ -18,7 +18,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import facenet_oracle as fo  # noqa: E402
-from tests.util_data import c1_images, structured_images, triplet_pool  # noqa: E402
+from tests.util_data import b90_batch, c1_images, structured_images, triplet_pool  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -26,11 +26,6 @@ OUT = os.path.join(ROOT, "tests", "golden")
 B90_LAYERS = ("conv2d/Conv2d_1a_3x3/kernel", "conv2d/Conv2d_4b_3x3/kernel", "block35/2/up/kernel",
               "reduction_a/tower_conv1/Conv2d_0b_3x3/kernel", "block17/4/tower_conv1/Conv2d_0b_1x7/kernel", "block17/9/up/kernel",
               "block8/2/up/kernel", "features/logits/kernel")
-
-
-def b90_batch(step: int) -> np.ndarray:
-    """The 90-image (30 triplets, rows a,p,n) batch of trajectory step `step`: seeded structured images, a fresh batch per step."""
-    return structured_images(90, seed=900 + step)
 
 
 def section_c1():

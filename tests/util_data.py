@@ -33,3 +33,9 @@ def triplet_pool(P=45, K=4, E=128, seed=0):
     emb = (centers.repeat(K, 1) * 0.04 + rng.normal(size=(P, K, E)).astype(np.float32) * 0.05).reshape(P * K, E)
     emb /= np.linalg.norm(emb, axis=1, keepdims=True)
     return emb.astype(np.float32), np.repeat(np.arange(P), K)
+
+
+def b90_batch(step: int):
+    """The 90-image (30 triplets, rows a,p,n) batch of step `step` of the batch-90 training trajectory
+    (tests/golden/train_trajectory_b90.npz): seeded structured images, a fresh batch per step."""
+    return structured_images(90, seed=900 + step)
