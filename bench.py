@@ -191,10 +191,10 @@ def kernel_roofline(trainer, miner, lib, dump=None, signature=None):
             g["bytes"] += sum(conv_bytes(d, opi) for d in descs)
             per_op.append(dict(op=op.name, kernel=key, us=round(ms * 1e3, 2), gflop=round(fl / 1e9, 3), layers=len(descs),
                                tflops=round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0))
-        elif kind == "conv_wgrad_grouped":
+        elif kind in ("conv_wgrad_grouped", "conv_wgrad_taps"):
             descs = op.keep[0]
             tname = "__bf16" if descs[0].dtype == 0 else "_Float16"
-            key = f"conv_wgrad_grouped_kernel<{tname},{op.name.split(':')[1].replace('x', ',')}>"
+            key = f"{kind}_kernel<{tname},{op.name.split(':')[1].replace('x', ',')}>"
             fl = sum(conv_flops(d, 2) for d in descs)
             g = groups.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, bound="mfma"))
             g["flops"] += fl

@@ -22,6 +22,7 @@
 //     and channel-slice output (ld_out) which makes tf.concat free.
 #include "common.h"
 #include "../../include/facenet_hip.h"
+#include "wgrad_taps.h"
 #include <cstdio>
 #include <cstdlib>
 
@@ -1058,6 +1059,7 @@ static int check_desc(const fn_conv_desc* d) {
 // wgrad: dW[co][kcol] += sum_m dY[m][co] * X[m @ tap(kcol)][ci(kcol)]
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
+    WgradOut out;   // first member: where the result goes (grouped launches; wgrad_reduce_kernel reads it through a byte stride)
     const unsigned short* x;
     const unsigned short* dy;
     float* dw;
@@ -1074,12 +1076,10 @@ struct WgradArgs {
     const float* nrm_beta;
     int nrm_sq_off, nrm_replicas, nrm_rep_stride, nrm_count;
     float nrm_eps;
-    // Grouped launches are DETERMINISTIC and atomic-free: a layer with one split stores its tiles straight into dw; a layer with
-    // several splits stores split z into slab z of `ws` ([splits][Cout*KTOT] fp32) and wgrad_reduce_kernel adds the slabs in
-    // order.  (Global float atomics run at ~1.3 TB/s at the memory side, plain stores at ~6 TB/s, and the order of atomic
-    // adds -- hence the rounding of dW -- changed from run to run.)  mode 0: legacy single launch, atomic accumulation into dw.
-    float* ws;
-    int store;   // 1: plain stores (dw or ws slab), 0: atomicAdd into dw
+    // Grouped launches are DETERMINISTIC and atomic-free (out.store = 1): a layer with one split stores its tiles straight into
+    // dw; a layer with several splits stores split z into slab z of out.ws and wgrad_reduce_kernel adds the slabs in order.
+    // (Global float atomics run at ~1.3 TB/s at the memory side, plain stores at ~6 TB/s, and the order of atomic adds -- hence
+    // the rounding of dW -- changed from run to run.)  out.store = 0: legacy single launch, atomic accumulation into dw.
 };
 
 // k-step pixel permutation shared by both operands: tile row of MFMA k index (g = lane>>4, h = half, q)
@@ -1268,7 +1268,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bx
     }
 
     // C layout: col = lane&15 (kcol), row = (lane>>4)*4 + r (cout)
-    float* const dst = a.ws ? a.ws + (long)bz * a.Cout * a.KTOT : a.dw;
+    float* const dst = a.out.ws ? a.out.ws + (long)bz * a.Cout * a.KTOT : a.dw;
 #pragma unroll
     for (int i = 0; i < MREP; ++i)
 #pragma unroll
@@ -1278,23 +1278,32 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bx
             for (int r = 0; r < 4; ++r) {
                 const int co = c0 + wm * TM + i * 16 + g * 4 + r;
                 if (co < a.Cout && kc < a.KTOT) {
-                    if (a.store) dst[(long)co * a.KTOT + kc] = acc[i][j][r];
+                    if (a.out.store) dst[(long)co * a.KTOT + kc] = acc[i][j][r];
                     else unsafeAtomicAdd(&a.dw[(long)co * a.KTOT + kc], acc[i][j][r]);
                 }
             }
         }
 }
 
-// Second stage of the grouped weight gradients: dw = slab 0 + slab 1 + ... in that order (blockIdx.y = layer).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs* __restrict__ args) {
-    const WgradArgs& a = args[blockIdx.y];
+// Second stage of the grouped weight gradients: dw = slab 0 + slab 1 + ... in that order (blockIdx.y = layer; the per-layer
+// records of either weight-gradient kernel start with a WgradOut and are `stride` bytes apart).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const unsigned char* __restrict__ args, int stride) {
+    const WgradOut a = *reinterpret_cast<const WgradOut*>(args + (long)blockIdx.y * stride);
     if (a.ws == nullptr) return;
-    const long n4 = (long)a.Cout * a.KTOT / 4;          // layer sizes are multiples of 8
+    const long n4 = (long)a.Cout * a.KTOT / 4;          // layer sizes are multiples of 4
     const f32x4* ws = reinterpret_cast<const f32x4*>(a.ws);
     f32x4* dw = reinterpret_cast<f32x4*>(a.dw);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         f32x4 s = ws[i];
-        for (int z = 1; z < a.splits; ++z) s += ws[(long)z * n4 + i];
+        int z = 1;
+        for (; z + 8 <= a.splits; z += 8) {       // eight slab reads in flight, added in slab order
+            f32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = ws[(long)(z + k) * n4 + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; z < a.splits; ++z) s += ws[(long)z * n4 + i];
         dw[i] = s;
     }
 }
@@ -1309,15 +1318,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 // workgroups per launch instead of 133 launches that each fill a fraction of the 256 CUs.
 // args[g] describes layer g; prefix[g] .. prefix[g+1] are its workgroups (gx * gy * splits).
 template <typename T, int BMW, int BNW, bool NORM>
-__global__ __launch_bounds__(256) void conv_wgrad_grouped_kernel(const WgradArgs* __restrict__ args, const int* __restrict__ prefix, int n) {
+__global__ __launch_bounds__(256) void conv_wgrad_grouped_kernel(const unsigned char* __restrict__ args_raw, int stride, const int* __restrict__ prefix, int n) {
     const int bid = blockIdx.x;
     int lo = 0, hi = n;                    // largest g with prefix[g] <= bid
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (prefix[mid] <= bid) lo = mid; else hi = mid;
     }
-    lo = __builtin_amdgcn_readfirstlane(lo);           // wave-uniform: scalar loads of args[lo]
-    const WgradArgs a = args[lo];
+    lo = __builtin_amdgcn_readfirstlane(lo);           // wave-uniform: scalar loads of the record
+    const WgradArgs a = *reinterpret_cast<const WgradArgs*>(args_raw + (long)lo * stride);
     // Workgroups that share a pixel chunk (same split, all gx*gy tiles) are consecutive in the layer's logical order: inside
     // the layer give every XCD a contiguous run of it, so a chunk of X / dY is fetched into one L2 instead of all eight
     // (per layer, not per launch: whole layers on one XCD would unbalance the chip).
@@ -1601,7 +1610,11 @@ extern "C" int fn_conv2d_wgrad(const fn_conv_desc* d, void* stream) {
 }
 
 // ---- grouped weight gradients ------------------------------------------------------------------------------------
-extern "C" int fn_conv2d_wgrad_arg_bytes(void) { return (int)sizeof(WgradArgs); }
+// one record size for both weight-gradient kernels (groups of either kind use the same host / device buffers)
+extern "C" int fn_conv2d_wgrad_arg_bytes(void) {
+    const size_t a = sizeof(WgradArgs), b = wgrad_taps_arg_bytes();
+    return (int)(((a > b ? a : b) + 15) / 16 * 16);
+}
 
 // Host-side planning: fills host_args[n * fn_conv2d_wgrad_arg_bytes()] and host_prefix[n+1] for n descriptors that all
 // dispatch to `variant` (= fn_conv2d_variant(desc, 2)); returns the total number of workgroups (or a negative status).
@@ -1609,10 +1622,25 @@ extern "C" int fn_conv2d_wgrad_group_build(const fn_conv_desc* descs, int n, int
                                            int64_t* ws_elems) {
     FN_REQUIRE(descs && host_args && host_prefix && ws_elems && n > 0, "wgrad_group_build: bad arguments");
     long ws_used = 0;
+    const size_t rec_bytes = (size_t)fn_conv2d_wgrad_arg_bytes();
+    if (variant >= WGRAD_TAPS_VARIANT) {      // tap-sharing kernel (conv_wgrad_taps.hip)
+        long total = 0;
+        for (int i = 0; i < n; ++i) {
+            if (int rc = check_desc(&descs[i])) return rc;
+            FN_REQUIRE(descs[i].dtype == descs[0].dtype, "wgrad_group_build: mixed dtypes");
+            host_prefix[i] = (int32_t)total;
+            const long wgs = wgrad_taps_plan(&descs[i], variant, reinterpret_cast<unsigned char*>(host_args) + i * rec_bytes, ws, &ws_used);
+            if (wgs < 0) return (int)wgs;
+            total += wgs;
+        }
+        FN_REQUIRE(total < (1L << 30), "wgrad_group_build: too many workgroups");
+        host_prefix[n] = (int32_t)total;
+        *ws_elems = ws_used;
+        return (int)total;
+    }
     const bool norm = variant >= 1000000;
     variant %= 1000000;
     const int bmw = variant / 1000, bnw = variant % 1000;
-    WgradArgs* out = reinterpret_cast<WgradArgs*>(host_args);
     long total = 0;
     for (int i = 0; i < n; ++i) {
         WgradArgs a;
@@ -1624,15 +1652,14 @@ extern "C" int fn_conv2d_wgrad_group_build(const fn_conv_desc* descs, int n, int
         FN_REQUIRE((a.nrm_stats != nullptr) == norm, "wgrad_group_build: descriptor %d: normalise-on-load members need a group of their own (variant + 1000000)", i);
         const int splits = plan_wgrad(a, descs[i].splits, bmw, bnw, true);
         FN_REQUIRE(((long)a.Cout * a.KTOT) % 4 == 0, "wgrad_group_build: descriptor %d: Cout*K must be a multiple of 4", i);
-        a.store = 1;
-        a.ws = nullptr;
+        a.out = WgradOut{a.dw, nullptr, a.Cout, a.KTOT, splits, 1};
         if (splits > 1) {            // slabs of this layer: [splits][Cout*KTOT]; ws == NULL on the sizing call
-            a.ws = ws ? ws + ws_used : reinterpret_cast<float*>(16);
+            a.out.ws = ws ? ws + ws_used : reinterpret_cast<float*>(16);
             ws_used += (long)splits * a.Cout * a.KTOT;
         }
         host_prefix[i] = (int32_t)total;
         total += (long)a.gx * a.gy * splits;
-        out[i] = a;
+        *reinterpret_cast<WgradArgs*>(reinterpret_cast<unsigned char*>(host_args) + i * rec_bytes) = a;
     }
     FN_REQUIRE(total < (1L << 30), "wgrad_group_build: too many workgroups");
     host_prefix[n] = (int32_t)total;
@@ -1642,7 +1669,8 @@ extern "C" int fn_conv2d_wgrad_group_build(const fn_conv_desc* descs, int n, int
 
 extern "C" int fn_conv2d_wgrad_reduce(const void* dev_args, int n, void* stream) {
     FN_REQUIRE(dev_args && n > 0 && n < 65536, "wgrad_reduce: bad arguments");
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(48, n), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const WgradArgs*>(dev_args));
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned char*>(dev_args),
+                       fn_conv2d_wgrad_arg_bytes());
     return check_launch("wgrad_reduce");
 }
 
@@ -1650,12 +1678,13 @@ template <typename T> static int launch_wgrad_grouped(const void* args, const in
     const bool norm = variant >= 1000000;     // +1000000: every member normalises x on load
     variant %= 1000000;
     const int bmw = variant / 1000, bnw = variant % 1000;
-    const WgradArgs* a = reinterpret_cast<const WgradArgs*>(args);
+    const unsigned char* a = reinterpret_cast<const unsigned char*>(args);
+    const int stride_ = fn_conv2d_wgrad_arg_bytes();
 #define FN_WG(BM_, BN_)                                                                                                     \
     if (bmw == BM_ && bnw == BN_) {                                                                                         \
         const size_t sm_ = 2 * 64 * ((BM_) * 2 + 32 + (BN_) * 2 + 32) + (norm ? 2 * (BN_) * 4 : 0);                            \
-        if (norm) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<T, BM_, BN_, true>), dim3(total), dim3(256), sm_, st, a, prefix, n); \
-        else hipLaunchKernelGGL((conv_wgrad_grouped_kernel<T, BM_, BN_, false>), dim3(total), dim3(256), sm_, st, a, prefix, n);    \
+        if (norm) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<T, BM_, BN_, true>), dim3(total), dim3(256), sm_, st, a, stride_, prefix, n); \
+        else hipLaunchKernelGGL((conv_wgrad_grouped_kernel<T, BM_, BN_, false>), dim3(total), dim3(256), sm_, st, a, stride_, prefix, n);    \
         return check_launch("conv_wgrad_grouped");                                                                          \
     }
     FN_WG(32, 64) FN_WG(32, 128) FN_WG(64, 64) FN_WG(64, 128) FN_WG(128, 64) FN_WG(128, 128)
@@ -1668,6 +1697,7 @@ extern "C" int fn_conv2d_wgrad_grouped(const void* dev_args, const int32_t* dev_
                                        void* stream) {
     FN_REQUIRE(dev_args && dev_prefix && n > 0 && total_blocks > 0, "wgrad_grouped: bad arguments");
     FN_REQUIRE(dtype == FN_BF16 || dtype == FN_F16, "dtype %d unsupported", dtype);
+    if (variant >= WGRAD_TAPS_VARIANT) return wgrad_taps_launch(dev_args, dev_prefix, n, total_blocks, variant, dtype, (hipStream_t)stream);
     return dtype == FN_BF16 ? launch_wgrad_grouped<__bf16>(dev_args, dev_prefix, n, total_blocks, variant, (hipStream_t)stream)
                             : launch_wgrad_grouped<_Float16>(dev_args, dev_prefix, n, total_blocks, variant, (hipStream_t)stream);
 }
@@ -1690,6 +1720,7 @@ extern "C" int fn_conv2d_variant(const fn_conv_desc* d, int op) {
         choose_conv_tile(d->N * d->H * d->W, d->Cin, valid_tile(d->tile_dgrad) ? d->tile_dgrad : 0, a, b);
         return variant_code(a, b, d->dy2 ? 1 : choose_conv_ks(d->N * d->H * d->W, d->Cin, d->KH * d->KW * d->Cout, a, b));
     }
+    if (const int tv = wgrad_taps_variant(d)) return tv;     // k x k layers on maps of >= 32 pixels: the tap-sharing kernel
     final_wgrad_tile(d->Cout, d->KH * d->KW * d->Cin, a, b);
     return a * 1000 + b;
 }

@@ -58,9 +58,11 @@ def group_wgrads(ops: List[Op], net: Network) -> List[Op]:
     groups = {}
     for op in singles:
         d = op.keep[0]
-        groups.setdefault((lib.fn_conv2d_variant(C.byref(d), 2) + (1000000 if d.nrm_stats else 0), d.dtype), []).append(op)
+        v = lib.fn_conv2d_variant(C.byref(d), 2)
+        groups.setdefault((v + (1000000 if d.nrm_stats and v < 5000000 else 0), d.dtype), []).append(op)
     nbytes = lib.fn_conv2d_wgrad_arg_bytes()
     out = list(rest)
+    split_tables, split_keep, split_writes = [], [], []
     for (variant, dt), members in sorted(groups.items()):
         n = len(members)
         descs = (_lib.ConvDesc * n)(*[m.keep[0] for m in members])
@@ -81,13 +83,22 @@ def group_wgrads(ops: List[Op], net: Network) -> List[Op]:
         for m in members:
             reads.extend(m.reads)
             writes.extend(m.writes)
-        out.append(Op(f"conv_wgrad_grouped:{variant % 1000000 // 1000}x{variant % 1000}" + (":norm" if variant >= 1000000 else ""),
-                      lib.fn_conv2d_wgrad_grouped,
+        if variant >= 5000000:      # tap-sharing kernel: 5000000 + BMW*1000 + taps*10 + (stride 2)
+            code = variant - 5000000
+            name = f"conv_wgrad_taps:{code // 1000}x{code % 1000 // 10}" + ("s2" if code % 10 else "")
+        else:
+            name = f"conv_wgrad_grouped:{variant % 1000000 // 1000}x{variant % 1000}" + (":norm" if variant >= 1000000 else "")
+        out.append(Op(name, lib.fn_conv2d_wgrad_grouped,
                       (_ptr(dev_args), _ptr(dev_prefix), n, total, variant, dt), keep=(descs, dev_args, dev_prefix, members, ws),
                       reads=tuple(reads), writes=tuple(writes) + (region(ws),)))
         if ws_elems.value > 0:
-            out.append(Op("conv_wgrad_reduce", lib.fn_conv2d_wgrad_reduce, (_ptr(dev_args), n), keep=(dev_args, ws),
-                          reads=(region(ws),), writes=tuple(writes)))
+            split_tables.append(dev_args)
+            split_keep.append(ws)
+            split_writes.extend(writes)
+    if split_tables:      # ONE ordered slab reduction for the split layers of every group (records of both kernels share a layout)
+        table = torch.cat(split_tables)
+        out.append(Op("conv_wgrad_reduce", lib.fn_conv2d_wgrad_reduce, (_ptr(table), table.numel() // nbytes), keep=(table, split_keep),
+                      reads=tuple(region(w) for w in split_keep), writes=tuple(split_writes)))
     return out
 
 

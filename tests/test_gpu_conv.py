@@ -180,6 +180,72 @@ def test_conv_wgrad(lib, case, dt):
     assert rel_err(dw, ref) < 2e-5
 
 
+TAPS_CASES = [
+    # N, H, W, Cin, Cout, kh, kw, stride, ph, pw, ld_x, ld_y, variant
+    (2, 19, 19, 32, 64, 3, 3, 1, 0, 0, 32, 64, 5064090),       # 2b-like, 'valid'
+    (2, 17, 17, 32, 32, 3, 3, 1, 1, 1, 96, 32, 5064090),       # block35 3x3 'same', 32 couts, x is a channel slice of a wider buffer
+    (2, 37, 37, 80, 192, 3, 3, 1, 0, 0, 80, 192, 5064090),     # 4a: Cin = 80 -> the third 32-channel slice is half empty
+    (2, 35, 35, 192, 256, 3, 3, 2, 0, 0, 192, 640, 5064090),   # 4b-like stride 2, dy is a channel slice of a concat buffer
+    (2, 17, 17, 256, 384, 3, 3, 2, 0, 0, 256, 384, 5064090),   # reduction_a stride 2 (17 -> 8)
+    (3, 8, 8, 128, 128, 1, 7, 1, 0, 3, 128, 128, 5064090),     # block17 1x7
+    (3, 8, 8, 128, 128, 7, 1, 1, 3, 0, 128, 256, 5064090),     # block17 7x1
+    (1, 45, 39, 32, 40, 3, 3, 1, 1, 1, 32, 40, 5064090),       # ragged tiles, Cout = 40 (one partly empty cout tile)
+]
+
+
+@pytest.mark.parametrize("dt", [_lib.FN_BF16, _lib.FN_F16])
+@pytest.mark.parametrize("case", TAPS_CASES)
+def test_conv_wgrad_tap_sharing_kernel(lib, case, dt):
+    """conv_wgrad_taps_kernel (k x k layers on maps of >= 32 pixels; grouped path only): dW against an fp32 CPU convolution
+    gradient on the same rounded operands -- unsplit (direct stores), split over pixels (slabs + ordered reduce), and
+    bit-identical from run to run."""
+    N, H, W, Cin, Cout, kh, kw, s, ph, pw, ld_x, ld_y, variant = case
+    d = conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt, ld_x=ld_x, ld_y=ld_y)
+    xb = _mk((N, H, W, ld_x), dt, seed=61)
+    dyb = _mk((N, d.OH, d.OW, ld_y), dt, seed=62)
+    x0, y0 = (ld_x - Cin) // 2 // 8 * 8, (ld_y - Cout) // 2 // 8 * 8      # the slice starts inside the buffer
+    x, dy = xb[..., x0:x0 + Cin], dyb[..., y0:y0 + Cout]
+    dw = torch.full((Cout, kh, kw, Cin), float("nan"), dtype=torch.float32, device="cuda")
+    d.x, d.y, d.dw = ptr(xb, x0), ptr(dyb, y0), ptr(dw)
+    assert lib.fn_conv2d_variant(C.byref(d), 2) == variant
+    wr = torch.zeros(Cout, Cin, kh, kw, requires_grad=True)
+    yr = torch.nn.functional.conv2d(x.float().cpu().permute(0, 3, 1, 2), wr, None, stride=s, padding=(ph, pw))
+    yr.backward(dy.float().cpu().permute(0, 3, 1, 2))
+    ref = wr.grad.permute(0, 2, 3, 1)
+    nbytes = lib.fn_conv2d_wgrad_arg_bytes()
+    for splits in (1, 3, 0):                       # 0: the library's own choice
+        d.splits = splits
+        arr = (_lib.ConvDesc * 1)(d)
+        host_args, host_prefix, ws_elems = (C.c_uint8 * nbytes)(), (C.c_int32 * 2)(), C.c_int64(0)
+        total = lib.fn_conv2d_wgrad_group_build(arr, 1, variant, host_args, host_prefix, None, C.byref(ws_elems))
+        nslabs = ws_elems.value // dw.numel()        # a layer cannot be split into more pieces than it has pixel tiles
+        assert total > 0 and ws_elems.value % dw.numel() == 0 and (splits != 1 or nslabs == 0) and (splits != 3 or 2 <= nslabs <= 3)
+        ws = torch.full((max(1, ws_elems.value),), float("nan"), device="cuda")
+        total = lib.fn_conv2d_wgrad_group_build(arr, 1, variant, host_args, host_prefix, ptr(ws), C.byref(ws_elems))
+        dev_args = torch.frombuffer(bytearray(host_args), dtype=torch.uint8).cuda()
+        dev_prefix = torch.tensor(list(host_prefix), dtype=torch.int32, device="cuda")
+        runs = []
+        for _ in range(2):
+            dw.fill_(float("nan"))
+            _lib.check(lib.fn_conv2d_wgrad_grouped(ptr(dev_args), ptr(dev_prefix), 1, total, variant, dt, stream()))
+            _lib.check(lib.fn_conv2d_wgrad_reduce(ptr(dev_args), 1, stream()))
+            torch.cuda.synchronize()
+            runs.append(dw.clone())
+        assert rel_err(runs[0], ref) < 2e-5, splits
+        assert torch.equal(runs[0], runs[1])
+    # the single-layer launch of the same descriptor (general kernel, atomics) agrees
+    d.splits = 0
+    dw.zero_()
+    _lib.check(lib.fn_conv2d_wgrad(C.byref(d), stream()))
+    torch.cuda.synchronize()
+    assert rel_err(dw, runs[0]) < 2e-5
+    # layers the kernel does not take: 3x3 maps, fewer than 32 input channels, 1x1
+    for (hh, cin, k) in ((3, 192, 3), (19, 8, 3), (17, 64, 1)):
+        e = conv_desc(2, hh, hh, cin, 64, k, k, 1, k // 2, k // 2, dt)
+        e.x = e.y = e.dw = ptr(dw)
+        assert lib.fn_conv2d_variant(C.byref(e), 2) < 5000000
+
+
 def test_conv_rejects_bad_geometry(lib):
     d = conv_desc(1, 8, 8, 12, 16, 3, 3, 1, 0, 0, _lib.FN_BF16)   # Cin not a multiple of 8
     x = torch.zeros(1, 8, 8, 12, dtype=torch.bfloat16, device="cuda")
@@ -192,7 +258,10 @@ def test_conv_wgrad_grouped_matches_single_launches(lib):
     """fn_conv2d_wgrad_grouped: several layers of one tile variant in ONE launch == the per-layer launches."""
     dt = _lib.FN_BF16
     cases = [(3, 8, 8, 128, 128, 1, 7, 1, 0, 3), (3, 8, 8, 896, 128, 1, 1, 1, 0, 0), (2, 17, 17, 192, 192, 3, 3, 1, 1, 1),
-             (5, 3, 3, 192, 192, 3, 1, 1, 1, 0), (2, 17, 17, 192, 256, 3, 3, 2, 0, 0)]
+             (5, 3, 3, 192, 192, 3, 1, 1, 1, 0), (2, 17, 17, 192, 256, 3, 3, 2, 0, 0),
+             # second and third members for every tap-sharing variant (records of a group are fn_conv2d_wgrad_arg_bytes() apart)
+             (2, 19, 19, 64, 64, 3, 3, 1, 0, 0), (1, 33, 21, 96, 128, 3, 3, 1, 1, 1), (2, 17, 17, 64, 96, 3, 3, 2, 0, 0),
+             (3, 8, 8, 128, 128, 7, 1, 1, 3, 0), (2, 9, 12, 64, 80, 1, 7, 1, 0, 3), (4, 17, 17, 256, 32, 1, 1, 1, 0, 0)]
     descs, keep, singles = [], [], []
     for i, (N, H, W, Cin, Cout, kh, kw, s, ph, pw) in enumerate(cases):
         d = conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt)
@@ -207,7 +276,7 @@ def test_conv_wgrad_grouped_matches_single_launches(lib):
     groups = {}
     for d, k in zip(descs, keep):
         groups.setdefault(lib.fn_conv2d_variant(C.byref(d), 2), []).append((d, k))
-    assert len(groups) >= 1
+    assert len(groups) >= 1 and [len(m) for v, m in groups.items() if v >= 5000000] == [8]
     nbytes = lib.fn_conv2d_wgrad_arg_bytes()
     for variant, members in groups.items():
         n = len(members)
