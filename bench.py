@@ -124,7 +124,14 @@ def _mangle_hint(demangled):
     return f"{m.group(1)}I{'DF16b' if m.group(2) == '__bf16' else 'DF16_'}{args}E"
 
 
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+def latest_profile(suffix):
+    """profiles/rNN_<suffix> of the highest round that has one (the run's tile choices and PMC passes belong together)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{suffix}")))
+    return found[-1] if found else os.path.join(ROOT, "profiles", f"r00_{suffix}")
+
+
+PMC_PROFILE = latest_profile("pmc_hbm_traffic.json")
 
 
 def tile_signature(*tile_dicts):
@@ -146,21 +153,56 @@ def pmc_traffic(kernel_key, signature):
     path = PMC_PROFILE
     if os.path.exists(path) and json.load(open(path)).get("tile_signature") != signature:
         return None
+    if not os.path.exists(path):
+        return None
+    tn = {"__bf16": "DF16b", "_Float16": "DF16_"}
     m = re.match(r"(conv_igemm_kernel|conv_igemm_grouped_kernel|conv_wgrad_kernel|conv_wgrad_grouped_kernel)"
                  r"<(__bf16|_Float16),(\d+),(\d+)(?:,ks=(\d))?(?:,1x1=(\d))?>", kernel_key)
-    if not (m and os.path.exists(path)):
+    f = re.match(r"(block17_infer_kernel|block35_infer_kernel|block8_infer_kernel|conv_wgrad_taps_kernel|conv_halo_kernel|bn_relu_fwd_kernel|"
+                 r"bn_relu_bwd_apply_kernel|adam_keras_kernel)<(__bf16|_Float16)", kernel_key)
+    if m:
+        tname = tn[m.group(2)]
+        if "wgrad" in m.group(1):      # <T, BMW, BNW, NORM>
+            pat = re.compile(rf"{m.group(1)}I{tname}Li{m.group(3)}ELi{m.group(4)}ELb0EE")
+        else:                          # <T, BM, BN, WM, WN, DEPTH, KS, PLAIN, MODE>
+            pat = re.compile(rf"{m.group(1)}I{tname}Li{m.group(3)}ELi{m.group(4)}ELi\d+ELi\d+ELi\d+ELi{m.group(5) or 1}ELb{m.group(6)}ELi0EE")
+    elif f:                            # one instantiation per dtype: mangled <kernel>I<type>..., demangled <kernel><<type>...
+        pat = re.compile(rf"{f.group(1)}(I{tn[f.group(2)]}|<{f.group(2)})")
+    else:
         return None
-    tname = "DF16b" if m.group(2) == "__bf16" else "DF16_"
-    if "wgrad" in m.group(1):      # <T, BMW, BNW, NORM>
-        pat = re.compile(rf"{m.group(1)}I{tname}Li{m.group(3)}ELi{m.group(4)}ELb0EE")
-    else:                          # <T, BM, BN, WM, WN, DEPTH, KS, PLAIN, MODE>
-        pat = re.compile(rf"{m.group(1)}I{tname}Li{m.group(3)}ELi{m.group(4)}ELi\d+ELi\d+ELi\d+ELi{m.group(5) or 1}ELb{m.group(6)}ELi0EE")
     n = tot = 0.0
     for name, v in json.load(open(path))["kernels"].items():
         if pat.search(name) or pat.search(_mangle_hint(name)):
             n += v["launches"]
             tot += v["launches"] * v["hbm_bytes_per_launch"]
     return round(tot / n) if n else None
+
+
+def other_op_model(op, kind, net):
+    """(kernel key, algorithmic FLOPs, algorithmic HBM bytes) of the launches that are not plain convolutions.
+    Fused inference blocks (csrc/block_fused.hip): 2 * MACs of the block's layers (SURVEY.md shape table: Block35 22.2, Block17 44.0,
+    Block8 14.4 M MAC per image); bytes = trunk in + out once, weights once.  Streaming kernels: the bytes they must touch."""
+    tn = lambda dt: "__bf16" if dt == 0 else "_Float16"
+    a = op.args
+    if kind in ("block17_fused", "block35_fused", "block8_fused"):
+        pre = op.name.split(":", 1)[1]
+        Ls = [L for n, L in net.layers.items() if n.startswith(pre + "/")]
+        hw = {"block17_fused": 64, "block35_fused": 289, "block8_fused": 9}[kind]
+        N = a[2]
+        macs = sum(L.numel for L in Ls) * hw * N
+        chans = Ls[-1].cout                     # `up` restores the trunk width
+        by = 2.0 * N * hw * chans * 2 + 2.0 * sum(L.numel for L in Ls)
+        return f"{kind.replace('_fused', '_infer_kernel')}<{tn(a[-1])}>", 2.0 * macs, by
+    if kind == "bn_relu_fwd":                   # (raw, ld, act, ld, M, C, ...): read y, write z
+        return f"bn_relu_fwd_kernel<{tn(a[-1])}>", 0.0, 4.0 * a[4] * a[5]
+    if kind == "bn_relu_bwd":                   # (dz, ld, y, ld, M, C, ...): read dz and y, write dy in place
+        return f"bn_relu_bwd_apply_kernel<{tn(a[-1])}>", 0.0, 6.0 * a[4] * a[5]
+    if kind == "adam_keras":                    # w, g, m, v read; w, m, v written; low-precision pack written
+        return f"adam_keras_kernel<{tn(a[-1])}>", 0.0, 28.0 * a[6] + 2.0 * a[5]
+    if kind == "conv_wgrad_reduce":
+        ws = op.keep[1]
+        return "wgrad_reduce_kernel", 0.0, 4.0 * sum(w.numel() for w in ws) + 4.0 * net.n_kernel
+    return kind, 0.0, 0.0
 
 
 def kernel_roofline(trainer, miner, lib, dump=None, signature=None):
@@ -221,8 +263,12 @@ def kernel_roofline(trainer, miner, lib, dump=None, signature=None):
                                tflops=round(conv_flops(d, opi) / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0,
                                shape=f"N{d.N} {d.H}x{d.W}x{d.Cin}->{d.OH}x{d.OW}x{d.Cout} k{d.KH}x{d.KW}s{d.stride}"))
         else:
-            g = groups.setdefault(kind, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, bound="hbm"))
-            per_op.append(dict(op=op.name, us=round(ms * 1e3, 2)))
+            key, fl, by = other_op_model(op, kind, net)
+            g = groups.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, bound="mfma" if fl else "hbm"))
+            g["flops"] += fl
+            g["bytes"] += by
+            per_op.append(dict(op=op.name, kernel=key, us=round(ms * 1e3, 2), **({"gflop": round(fl / 1e9, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 1)} if fl else {}),
+                               **({"gbs": round(by / (ms * 1e-3) / 1e9, 1)} if by and ms > 0 else {})))
         g["ms"] += ms
         g["ms_burst"] = g.get("ms_burst", 0.0) + msb
         g["launches"] += 1
@@ -232,7 +278,9 @@ def kernel_roofline(trainer, miner, lib, dump=None, signature=None):
             json.dump(per_op, f, indent=0)
     total_ms = sum(g["ms"] for g in groups.values())
     top = sorted(groups.items(), key=lambda kv: -kv[1]["ms"])
-    name, g = next((kv for kv in top if kv[1]["flops"] > 0), top[0])
+    # the dominant instantiation by summed in-step time -- convolution, fused block or streaming kernel alike (every group that can
+    # top the list carries its algorithmic flops / bytes: other_op_model)
+    name, g = next((kv for kv in top if kv[1]["flops"] > 0 or kv[1]["bytes"] > 0), top[0])
     # the roofline that binds the dominant kernel: the larger of (algorithmic flops / MFMA peak) and (algorithmic bytes /
     # HBM peak) is the time it cannot beat; the other one is reported under "other_roofline"
     sec = g["ms"] * 1e-3
@@ -251,7 +299,8 @@ def kernel_roofline(trainer, miner, lib, dump=None, signature=None):
         "other_roofline": other,
     }
     breakdown = [{"kernel": k, "ms": round(v["ms"], 3), "launches": v["launches"],
-                  **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} if v["flops"] > 0 and v["ms"] > 0 else {})}
+                  **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} if v["flops"] > 0 and v["ms"] > 0 else {}),
+                  **({"gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if v["bytes"] > 0 and v["ms"] > 0 else {})}
                  for k, v in top[:12]]
     return roof, breakdown, total_ms
 
@@ -389,11 +438,11 @@ def main():
     if args.dry_run:
         return dry_run(args)
 
-    # the tile choices of the committed profiles (profiles/r02_tile_cache.json: one autotune run on an MI355X) are reused when
+    # the tile choices of the committed profiles (profiles/rNN_tile_cache.json of the latest round: one autotune run on an MI355X) are reused when
     # present: the run then launches the kernel variants the rocprofv3 passes under profiles/ measured (roofline.traffic), starts
     # faster and is reproducible.  FACENET_TUNE_CACHE= (empty) re-tunes from scratch.
-    if "FACENET_TUNE_CACHE" not in os.environ and os.path.exists(os.path.join(ROOT, "profiles", "r02_tile_cache.json")):
-        os.environ["FACENET_TUNE_CACHE"] = os.path.join(ROOT, "profiles", "r02_tile_cache.json")
+    if "FACENET_TUNE_CACHE" not in os.environ and os.path.exists(latest_profile("tile_cache.json")):
+        os.environ["FACENET_TUNE_CACHE"] = latest_profile("tile_cache.json")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # one process per GPU; FACENET_DIST_BACKEND=gloo lets the whole data-parallel path be rehearsed with several ranks on

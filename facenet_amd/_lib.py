@@ -81,6 +81,7 @@ _SIGNATURES = {
     "fn_avgpool_fwd": [_p, _p, _i, _i, _i, _i, _p],
     "fn_avgpool_bwd": [_p, _p, _i, _i, _i, _i, _p],
     "fn_residual_bwd": [_p, _p, _p, _p, _p, _i, _i, _f, _i, _i, _i, _p],
+    "fn_acc_to_float": [_p, _p, _l, _i, _p],
     "fn_head_bn_fwd": [_p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _f, _f, _p],
     "fn_head_bn_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "fn_l2norm_fwd": [_p, _p, _i, _i, _f, _p],

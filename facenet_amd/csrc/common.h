@@ -101,22 +101,32 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- order-independent accumulation ----------------------------------------------------------------------------------------
+// Sums that many workgroups contribute to (BatchNorm batch statistics, the BatchNorm-backward sums, bias gradients, losses) are
+// accumulated as 64-bit FIXED-POINT integers: every contribution is an fp32 partial sum computed in a fixed order, converted once
+// (round to nearest) and added with an integer atomic.  Integer addition is associative, so the total has the same bits whatever
+// order the workgroups arrive in -- fp32 atomics gave training results that differed from run to run (and two data-parallel
+// replicas that were only equal "within the atomics' noise").  Two scales: forward statistics (sums of activations and their
+// squares over up to 5e5 pixels: |total| < 2^43 = 8.8e12, resolution 2^-20) and gradient sums (|total| < 2^23 = 8.4e6, resolution
+// 2^-40 = 9e-13).  fn_acc_t in the C ABI.
+typedef int64_t acc_t;      // == fn_acc_t of the C ABI
+enum { ACC_STAT = 20, ACC_GRAD = 40 };
+template <int FRAC> __device__ __forceinline__ void acc_add(acc_t* p, float v) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn((double)v * (double)(1ll << FRAC)));
+}
+template <int FRAC> __device__ __forceinline__ float acc_get(acc_t a) { return (float)((double)a * (1.0 / (double)(1ll << FRAC))); }
+
 // BatchNorm batch statistics -> affine (center only): scale = rstd, shift = beta - mean*rstd.  One definition for the
-// materialising kernel, the normalise-on-load operand path and fn_bn_finalize: replica sums in four interleaved partials
-// (independent loads in flight), combined left to right, so all three produce the same bits.
-__device__ __forceinline__ void bn_batch_affine(const float* __restrict__ stats, int c, int sq_off, int reps, int rep_stride, int count,
+// materialising kernel, the normalise-on-load operand path and fn_bn_finalize (the replicas hold fixed-point integers: their sum
+// is exact in any order, so all three produce the same bits).
+__device__ __forceinline__ void bn_batch_affine(const acc_t* __restrict__ stats, int c, int sq_off, int reps, int rep_stride, int count,
                                                 float eps, float beta, float& scale, float& shift, float& mean, float& var) {
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int rp = 0; rp < reps; rp += 4) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (rp + k < reps) {
-                s[k] += stats[(long)(rp + k) * rep_stride + c];
-                q[k] += stats[(long)(rp + k) * rep_stride + sq_off + c];
-            }
+    acc_t s = 0, q = 0;       // replica sums are integer: exact, any order
+    for (int rp = 0; rp < reps; ++rp) {
+        s += stats[(long)rp * rep_stride + c];
+        q += stats[(long)rp * rep_stride + sq_off + c];
     }
-    const float s1 = s[0] + s[1] + s[2] + s[3];
-    const float s2 = q[0] + q[1] + q[2] + q[3];
+    const float s1 = acc_get<ACC_STAT>(s), s2 = acc_get<ACC_STAT>(q);
     const float inv = 1.f / (float)count;
     mean = s1 * inv;
     var = fmaxf(s2 * inv - mean * mean, 0.f);

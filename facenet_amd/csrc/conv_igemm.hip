@@ -33,7 +33,7 @@ struct ConvArgs {
     const unsigned short* wp;   // packed weights [NOUT][KTOT]
     void* out;
     const float* bias;
-    float* stats;
+    acc_t* stats;               // BatchNorm batch statistics (fixed point, ACC_STAT): stats[rep*stride + c] += sum y, [.. + sq_off + c] += sum y^2
     const unsigned short* resid;
     int M, PH, PW;   // output pixels = N*PH*PW
     int SH, SW;      // source spatial dims
@@ -51,7 +51,7 @@ struct ConvArgs {
     const float* bn_scale;
     const float* bn_shift;
     const float* bn_beta;
-    float* bn_acc;                // acc[rep*stride + c] += sum dyh ; acc[rep*stride + sq_off + c] += sum dyh*xhat
+    acc_t* bn_acc;                // fixed point (ACC_GRAD): acc[rep*stride + c] += sum dyh ; acc[rep*stride + sq_off + c] += sum dyh*xhat
     int ld_bn_y, bn_sq_off, bn_replicas, bn_rep_stride, bn_relu;
     // stride-2 dgrad: output pixels are split into 4 parity classes ((iy+pad)&1, (ix+pad)&1); a class only sees the taps
     // of matching parity, so each class is its own GEMM (M = its pixels, K = its taps) inside one launch.
@@ -68,7 +68,7 @@ struct ConvArgs {
     const unsigned short* src3; const unsigned short* wp3;
     int K2, ld2, K3, ld3, t1, t2, nt_total, src2_bytes, w2_bytes, src3_bytes, w3_bytes;
     // normalise-on-load (forward only): src is the raw output of a BN(center)+ReLU layer, see fn_conv_desc.nrm_*
-    const float* nrm_stats;
+    const acc_t* nrm_stats;
     const float* nrm_beta;
     int nrm_sq_off, nrm_replicas, nrm_rep_stride, nrm_count;
     float nrm_eps;
@@ -77,7 +77,7 @@ struct ConvArgs {
     int halo_ty, halo_tx;         // halo kernel: 8x16-pixel output tiles per image (rows, columns)
     const unsigned short* mask;   // rows of the block's forward output: values <= 0 zero the gradient
     unsigned short* out2;         // scale2 * (masked gradient), geometry of out
-    float* colsum;                // += column sums of what goes to out2
+    acc_t* colsum;                // fixed point (ACC_GRAD): += column sums of what goes to out2
     float scale2;
     const float* prelu;           // forward: per-output-channel PReLU slope applied to conv + bias
 };
@@ -138,9 +138,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
             q += __shfl_xor(q, 16);
             s += __shfl_xor(s, 32);
             q += __shfl_xor(q, 32);
-            if (lane < 16) {
-                atomicAdd(&sRed[wn * TN + j * 16 + lane], s);
-                atomicAdd(&sRed[BN + wn * TN + j * 16 + lane], q);
+            if (lane < 16) {      // slot [wm]: one writer per (row wave, column) -- no LDS atomics, the WM partials are added in order below
+                sRed[wm * 2 * BN + wn * TN + j * 16 + lane] = s;
+                sRed[wm * 2 * BN + BN + wn * TN + j * 16 + lane] = q;
             }
         }
     }
@@ -284,19 +284,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
 #pragma unroll 8
                 for (int t = 0; t < RP; ++t) sum += sP[t * 2 * BN + tid];
                 if (a.out2) {
-                    if (tid < BN) atomicAdd(&a.colsum[n0 + c], sum);
+                    if (tid < BN) acc_add<ACC_GRAD>(&a.colsum[n0 + c], sum);
                 } else {
-                    float* ap = a.bn_acc + (long)(tm % a.bn_replicas) * a.bn_rep_stride + (tid < BN ? 0 : a.bn_sq_off);
-                    atomicAdd(&ap[n0 + c], sum);
+                    acc_t* ap = a.bn_acc + (long)(tm % a.bn_replicas) * a.bn_rep_stride + (tid < BN ? 0 : a.bn_sq_off);
+                    acc_add<ACC_GRAD>(&ap[n0 + c], sum);
                 }
             }
         }
     }
     if (a.stats && tid < BN && n0 + tid < a.NOUT) {
         // global float atomics to one address serialise at the memory side: spread the row tiles over replicas
-        float* sp = a.stats + (long)(tm % a.stats_replicas) * a.stats_rep_stride;
-        atomicAdd(&sp[n0 + tid], sRed[tid]);
-        atomicAdd(&sp[a.stats_sq_off + n0 + tid], sRed[BN + tid]);
+        // (integer atomics to one address serialise at the memory side like float ones: the replicas stay)
+        acc_t* sp = a.stats + (long)(tm % a.stats_replicas) * a.stats_rep_stride;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { s1 += sRed[w * 2 * BN + tid]; s2 += sRed[w * 2 * BN + BN + tid]; }
+        acc_add<ACC_STAT>(&sp[n0 + tid], s1);
+        acc_add<ACC_STAT>(&sp[a.stats_sq_off + n0 + tid], s2);
     }
 }
 
@@ -328,8 +332,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     unsigned char* sA = smem + grp * STAGE_BYTES;
     unsigned char* sB = sA + 2 * A_BYTES;
     float* sC = reinterpret_cast<float*>(smem);
-    float* sRed = reinterpret_cast<float*>(smem + MAIN_BYTES);         // [2*BN]
-    int4* sT = reinterpret_cast<int4*>(smem + MAIN_BYTES + 2 * BN * 4);  // tap table [ceil(KTOT/64)*8] (general convolutions)
+    float* sRed = reinterpret_cast<float*>(smem + MAIN_BYTES);         // [WM <= 4][2*BN]: per-row-wave statistic partials
+    int4* sT = reinterpret_cast<int4*>(smem + MAIN_BYTES + 8 * BN * 4);  // tap table [ceil(KTOT/64)*8] (general convolutions)
 
     const int tid = threadIdx.x, gtid = tid & 255, lane = tid & 63, wave = gtid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -386,8 +390,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             sT[i] = t;
         }
     }
-    if (tid < 2 * BN) sRed[tid] = 0.f;
-
     const int kg = gtid & 7, r0 = gtid >> 3;
     int ry[AP], rx[AP];
     unsigned rbyte[AP], wbyte[BP];
@@ -586,22 +588,23 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         if constexpr (NORM) {
             // scale / shift of the source channels from the producer's statistic replicas -- AFTER the first operand loads have
             // been issued, so the two memory round trips overlap; (channel, replica quarter) pairs spread over all threads
-            float* sPart = reinterpret_cast<float*>(smem + grp * STAGE_BYTES);     // staging LDS is still free: [8][CS]
+            acc_t* sPart = reinterpret_cast<acc_t*>(smem + grp * STAGE_BYTES);     // staging LDS is still free: [4][CS] (<= 16 KB)
             const int CS = a.CS;
-            for (int i = tid; i < 4 * CS; i += NT) {
+            for (int i = tid; i < 2 * CS; i += NT) {
                 const int c = i % CS, q = i / CS;
-                float s1 = 0.f, s2 = 0.f;
-                for (int rp = q; rp < a.nrm_replicas; rp += 4) {
+                acc_t s1 = 0, s2 = 0;         // fixed-point replicas: integer sums, exact in any order
+                for (int rp = q; rp < a.nrm_replicas; rp += 2) {
                     s1 += a.nrm_stats[(long)rp * a.nrm_rep_stride + c];
                     s2 += a.nrm_stats[(long)rp * a.nrm_rep_stride + a.nrm_sq_off + c];
                 }
                 sPart[q * CS + c] = s1;
-                sPart[(4 + q) * CS + c] = s2;
+                sPart[(2 + q) * CS + c] = s2;
             }
             __syncthreads();
-            for (int c = tid; c < CS; c += NT) {      // same combination order as bn_batch_affine / bn_relu_fwd_kernel: same bits
-                const float s1 = sPart[c] + sPart[CS + c] + sPart[2 * CS + c] + sPart[3 * CS + c];
-                const float s2 = sPart[4 * CS + c] + sPart[5 * CS + c] + sPart[6 * CS + c] + sPart[7 * CS + c];
+            for (int c = tid; c < CS; c += NT) {      // same arithmetic as bn_batch_affine / bn_relu_fwd_kernel: same bits
+                const acc_t* sp = sPart;
+                const float s1 = acc_get<ACC_STAT>(sp[c] + sp[CS + c]);
+                const float s2 = acc_get<ACC_STAT>(sp[2 * CS + c] + sp[3 * CS + c]);
                 const float inv = 1.f / (float)a.nrm_count;
                 const float mean = s1 * inv;
                 const float var = fmaxf(s2 * inv - mean * mean, 0.f);
@@ -700,8 +703,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sP = smem;
     unsigned char* sW = smem + PATCH_BYTES;
-    float* sRed = reinterpret_cast<float*>(smem + MAIN_BYTES);
-    int* sRow = reinterpret_cast<int*>(smem + MAIN_BYTES + 2 * BN * 4);
+    float* sRed = reinterpret_cast<float*>(smem + MAIN_BYTES);         // [WM <= 4][2*BN]
+    int* sRow = reinterpret_cast<int*>(smem + MAIN_BYTES + 8 * BN * 4);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -718,7 +721,6 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a) {
     // source coordinates of patch pixel (0,0): forward taps run down/right (sk = +1), mirrored for the data gradient
     const int sy0 = oy0 + a.offy - (a.sk > 0 ? 0 : KH - 1), sx0 = ox0 + a.offx - (a.sk > 0 ? 0 : KW - 1);
 
-    if (tid < 2 * BN) sRed[tid] = 0.f;
     if (tid < BM) {
         const int py = tid >> 4, px = tid & 15;
         sRow[tid] = (oy0 + py < a.PH && ox0 + px < a.PW) ? (n * a.PH + oy0 + py) * a.PW + ox0 + px : -1;
@@ -826,7 +828,7 @@ static size_t halo_smem_bytes(int BN, int KH, int KW) {
     const int npix = (8 + KH - 1) * (16 + KW - 1);
     const int stage = (npix * 64 + 255) / 256 * 256 + KH * KW * BN * 64;
     const int cb = 128 * (BN + 4) * 4;
-    return (size_t)(stage > cb ? stage : cb) + 2 * BN * 4 + 128 * 4;
+    return (size_t)(stage > cb ? stage : cb) + 8 * BN * 4 + 128 * 4;
 }
 
 // which layers go to the halo kernel: stride-1 3x3 (forward or data gradient) on maps of at least 30 x 30 output pixels with at
@@ -896,7 +898,7 @@ static void plan_tiles(ConvArgs& a, int BM, int BN) {
 static size_t conv_smem_bytes(int BM, int BN, int KTOT, int plain, int norm_channels, int ks) {
     const int STAGE = ks * 2 * (BM * 128 + BN * 128);
     const int CB = BM * (BN + 4) * 4;
-    return (size_t)(STAGE > CB ? STAGE : CB) + 2 * BN * 4 + (plain ? 0 : (size_t)cdiv(KTOT, 64) * 8 * 16) + (size_t)BM * 4 +
+    return (size_t)(STAGE > CB ? STAGE : CB) + 8 * BN * 4 + (plain ? 0 : (size_t)cdiv(KTOT, 64) * 8 * 16) + (size_t)BM * 4 +
            (size_t)norm_channels * 8;
 }
 
@@ -1072,7 +1074,7 @@ struct WgradArgs {
     float inv_ow, inv_ohw;
     int x_bytes, dy_bytes;   // extents for the buffer resource descriptors (< 2^30)
     // normalise-on-load of x (see fn_conv_desc.nrm_*)
-    const float* nrm_stats;
+    const acc_t* nrm_stats;
     const float* nrm_beta;
     int nrm_sq_off, nrm_replicas, nrm_rep_stride, nrm_count;
     float nrm_eps;

@@ -17,7 +17,8 @@ __device__ __forceinline__ float ord2f(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
-// work per image: [0]=ord(max) [1]=ord(-min) [2]=sum [3]=sumsq   (zeroed by a memset node first; ord(x) > 0 always)
+// work per image (8 words): [0]=ord(max) [1]=ord(-min) [2..3]=sum [4..5]=sumsq as fixed-point acc_t (ACC_STAT: order-independent;
+// sums of u8 pixels are integers and exact)   (zeroed by a kernel node first; ord(x) > 0 always)
 // SRC = uint8_t (the reference's 'input' node dtype, facenet/__init__.py:16-20) or float (facenet.py:69 casts anyway)
 template <typename SRC>
 __global__ __launch_bounds__(256) void img_stats_kernel(const SRC* __restrict__ img, unsigned* __restrict__ work, int count) {
@@ -49,10 +50,10 @@ __global__ __launch_bounds__(256) void img_stats_kernel(const SRC* __restrict__ 
         }
     mx = wave_max(mx); mn = -wave_max(-mn); s = wave_sum(s); q = wave_sum(q);
     if ((threadIdx.x & 63) == 0) {
-        atomicMax(&work[4 * n + 0], f2ord(mx));
-        atomicMax(&work[4 * n + 1], f2ord(-mn));
-        atomicAdd(reinterpret_cast<float*>(&work[4 * n + 2]), s);
-        atomicAdd(reinterpret_cast<float*>(&work[4 * n + 3]), q);
+        atomicMax(&work[8 * n + 0], f2ord(mx));
+        atomicMax(&work[8 * n + 1], f2ord(-mn));
+        acc_add<ACC_STAT>(reinterpret_cast<acc_t*>(&work[8 * n + 2]), s);
+        acc_add<ACC_STAT>(reinterpret_cast<acc_t*>(&work[8 * n + 4]), q);
     }
 }
 
@@ -65,12 +66,12 @@ __global__ __launch_bounds__(256) void img_apply_kernel(const SRC* __restrict__ 
     //   mode 1: (x - mean) / max(std, 1/sqrt(numel))  per_image_standardization   facenet.py:79-80
     float mul, sub, den;
     if (mode == 0) {
-        const float mx = ord2f(work[4 * n + 0]), mn = -ord2f(work[4 * n + 1]);
+        const float mx = ord2f(work[8 * n + 0]), mn = -ord2f(work[8 * n + 1]);
         mul = 2.f; sub = mn + mx; den = fmaxf(mx - mn, 1e-3f);
     } else {
         const float cnt = (float)HW * 3.f;
-        const float mean = __uint_as_float(work[4 * n + 2]) / cnt;
-        const float var = fmaxf(__uint_as_float(work[4 * n + 3]) / cnt - mean * mean, 0.f);
+        const float mean = acc_get<ACC_STAT>(*reinterpret_cast<const acc_t*>(&work[8 * n + 2])) / cnt;
+        const float var = fmaxf(acc_get<ACC_STAT>(*reinterpret_cast<const acc_t*>(&work[8 * n + 4])) / cnt - mean * mean, 0.f);
         mul = 1.f; sub = mean; den = fmaxf(sqrtf(var), rsqrtf(cnt));
     }
     const SRC* p = img + (long)n * HW * 3;
@@ -131,11 +132,12 @@ __global__ __launch_bounds__(256) void gather_images_kernel(const uint8_t* __res
 // (same-address float atomics serialise) without every workgroup re-reading every channel.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* __restrict__ y, int ld_y, unsigned short* __restrict__ z,
-                                                          int ld_z, int M, int C, const float* __restrict__ stats, int sq_off, int reps, int rep_stride,
+                                                          int ld_z, int M, int C, const acc_t* __restrict__ stats, int sq_off, int reps, int rep_stride,
                                                           const float* __restrict__ beta, float* __restrict__ save_scale,
                                                           float* __restrict__ save_shift, float* __restrict__ mm, float* __restrict__ mv,
                                                           float momentum, float eps, int relu, int rows_per_block) {
-    __shared__ float s_scale[64], s_shift[64], s_part[4][2][64];
+    __shared__ float s_scale[64], s_shift[64];
+    __shared__ acc_t s_part[4][2][64];
     const int lin_ = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);   // rows -> XCD like the convolutions
     const int bx_ = lin_ / gridDim.y, by_ = lin_ - bx_ * gridDim.y;
     const int c0 = by_ * 64;
@@ -151,8 +153,9 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* 
     if (tx < ncg && r0 + ty < r1) pre = *reinterpret_cast<const u32x4*>(y + (long)(r0 + ty) * ld_y + c);
     {   // replica sums: 4 thread groups x 64 channels, independent loads in flight (a rolled serial loop would expose
         // one memory latency per replica)
+        // (the replicas are fixed-point integers: their sum is exact in any order)
         const int cc = threadIdx.x & 63, q = threadIdx.x >> 6;
-        float s1 = 0.f, s2v = 0.f;
+        acc_t s1 = 0, s2v = 0;
         if (c0 + cc < C) {
 #pragma unroll 4
             for (int rp = q; rp < reps; rp += 4) {
@@ -166,8 +169,8 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* 
     __syncthreads();
     if (threadIdx.x < 64 && c0 + threadIdx.x < C) {
         const int c = c0 + threadIdx.x;
-        const float s1 = s_part[0][0][threadIdx.x] + s_part[1][0][threadIdx.x] + s_part[2][0][threadIdx.x] + s_part[3][0][threadIdx.x];
-        const float s2v = s_part[0][1][threadIdx.x] + s_part[1][1][threadIdx.x] + s_part[2][1][threadIdx.x] + s_part[3][1][threadIdx.x];
+        const float s1 = acc_get<ACC_STAT>(s_part[0][0][threadIdx.x] + s_part[1][0][threadIdx.x] + s_part[2][0][threadIdx.x] + s_part[3][0][threadIdx.x]);
+        const float s2v = acc_get<ACC_STAT>(s_part[0][1][threadIdx.x] + s_part[1][1][threadIdx.x] + s_part[2][1][threadIdx.x] + s_part[3][1][threadIdx.x]);
         const float invM = 1.f / (float)M;
         const float mean = s1 * invM;
         const float var = fmaxf(s2v * invM - mean * mean, 0.f);
@@ -221,9 +224,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const unsigned short* __restrict__ dz, int ld_d,
                                                                  const unsigned short* __restrict__ y, int ld_y, int M, int C,
                                                                  const float* __restrict__ beta, const float* __restrict__ scale,
-                                                                 const float* __restrict__ shift, float* __restrict__ dbeta,
-                                                                 float* __restrict__ s2, int relu, int rows_per_block) {
-    // (dbeta, s2) here are the two halves of the accumulator workspace: acc[c] and acc[sq_off + c]
+                                                                 const float* __restrict__ shift, acc_t* __restrict__ dbeta,
+                                                                 acc_t* __restrict__ s2, int relu, int rows_per_block) {
+    // (dbeta, s2) here are the two halves of the fixed-point accumulator workspace: acc[c] and acc[sq_off + c]
     __shared__ float red[32][2 * 64 + 1];
     const int lin_ = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);   // rows -> XCD like the convolutions
     const int bx_ = lin_ / gridDim.y, by_ = lin_ - bx_ * gridDim.y;
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const unsigned 
             float s = 0.f;
 #pragma unroll 8
             for (int t = 0; t < 32; ++t) s += red[t][col];
-            atomicAdd(col < 64 ? &dbeta[c] : &s2[c], s);
+            acc_add<ACC_GRAD>(col < 64 ? &dbeta[c] : &s2[c], s);
         }
     }
 }
@@ -298,9 +301,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(unsigned short* 
                                                                 const unsigned short* __restrict__ y, int ld_y, int M, int C,
                                                                 const float* __restrict__ beta, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, float* __restrict__ dbeta,
-                                                                const float* __restrict__ acc, int sq_off, int reps, int rep_stride,
+                                                                const acc_t* __restrict__ acc, int sq_off, int reps, int rep_stride,
                                                                 int relu, int rows_per_block) {
-    __shared__ float s_k1[64], s_k2[64], s_part[4][2][64];
+    __shared__ float s_k1[64], s_k2[64];
+    __shared__ acc_t s_part[4][2][64];
     const int lin_ = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);   // rows -> XCD like the convolutions
     const int bx_ = lin_ / gridDim.y, by_ = lin_ - bx_ * gridDim.y;
     const int c0 = by_ * 64;
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(unsigned short* 
     }
     {
         const int cc = threadIdx.x & 63, q = threadIdx.x >> 6;
-        float s1 = 0.f, s2v = 0.f;
+        acc_t s1 = 0, s2v = 0;          // fixed-point replicas: exact integer sums
         if (c0 + cc < C) {
 #pragma unroll 4
             for (int rp = q; rp < reps; rp += 4) {
@@ -331,8 +335,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(unsigned short* 
     }
     __syncthreads();
     if (threadIdx.x < 64 && c0 + threadIdx.x < C) {
-        const float s1 = s_part[0][0][threadIdx.x] + s_part[1][0][threadIdx.x] + s_part[2][0][threadIdx.x] + s_part[3][0][threadIdx.x];
-        const float s2v = s_part[0][1][threadIdx.x] + s_part[1][1][threadIdx.x] + s_part[2][1][threadIdx.x] + s_part[3][1][threadIdx.x];
+        const float s1 = acc_get<ACC_GRAD>(s_part[0][0][threadIdx.x] + s_part[1][0][threadIdx.x] + s_part[2][0][threadIdx.x] + s_part[3][0][threadIdx.x]);
+        const float s2v = acc_get<ACC_GRAD>(s_part[0][1][threadIdx.x] + s_part[1][1][threadIdx.x] + s_part[2][1][threadIdx.x] + s_part[3][1][threadIdx.x]);
         const float invM = 1.f / (float)M;
         s_k1[threadIdx.x] = s1 * invM;
         s_k2[threadIdx.x] = s2v * invM;
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const unsigned short* 
 template <typename T>
 __global__ __launch_bounds__(256) void residual_bwd_kernel(const unsigned short* __restrict__ dout, const unsigned short* __restrict__ out,
                                                            unsigned short* __restrict__ dtrunk, unsigned short* __restrict__ dup,
-                                                           float* __restrict__ dbias, int M, int C, float scale, int relu, int accumulate,
+                                                           acc_t* __restrict__ dbias, int M, int C, float scale, int relu, int accumulate,
                                                            int rows_per_block) {
     __shared__ float red[32][64 + 1];
     const int lin_ = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);   // rows -> XCD like the convolutions
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(256) void residual_bwd_kernel(const unsigned short*
 #pragma unroll 8
         for (int t = 0; t < 32; ++t) s += red[t][threadIdx.x];
         const int c = c0 + threadIdx.x;
-        if (c < C) atomicAdd(&dbias[c], s);
+        if (c < C) acc_add<ACC_GRAD>(&dbias[c], s);
     }
 }
 
@@ -726,7 +730,7 @@ static int image_normalize_impl(const SRC* img, void* out, float* work, int N, i
     FN_REQUIRE(mode == 0 || mode == 1, "Invalid image normalization algorithm");  // facenet.py:82
     FN_REQUIRE(((uintptr_t)img & 15) == 0 && ((long)HW * 3 * sizeof(SRC)) % 16 == 0, "image_normalize: images must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;
-    fill_words(work, 0u, 0u, 4 * N, st);
+    fill_words(work, 0u, 0u, 8 * N, st);
     hipLaunchKernelGGL(img_stats_kernel<SRC>, dim3(8, N), dim3(256), 0, st, img, (unsigned*)work, HW * 3);
     const int gx = grid_for(HW, 256, 32);
     if (dtype == FN_BF16) hipLaunchKernelGGL((img_apply_kernel<__bf16, SRC>), dim3(gx, N), dim3(256), 0, st, img, (unsigned short*)out, (const unsigned*)work, HW, mode);
@@ -785,7 +789,7 @@ extern "C" int fn_gather_images(const uint8_t* pool, const int32_t* idx, uint8_t
     return check_launch("gather_images");
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int sq_off, int rep_stride, const int* __restrict__ reps,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const acc_t* __restrict__ stats, int sq_off, int rep_stride, const int* __restrict__ reps,
                                                           const int* __restrict__ count, const float* __restrict__ beta,
                                                           float* __restrict__ save_scale, float* __restrict__ save_shift,
                                                           float* __restrict__ mm, float* __restrict__ mv, float momentum, float eps, int CB) {
@@ -801,16 +805,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
-extern "C" int fn_bn_finalize(const float* stats, int sq_off, int rep_stride, const int32_t* reps, const int32_t* count, const float* beta,
+extern "C" int fn_bn_finalize(const fn_acc_t* stats, int sq_off, int rep_stride, const int32_t* reps, const int32_t* count, const float* beta,
                               float* save_scale, float* save_shift, float* moving_mean, float* moving_var, float momentum, float eps, int CB,
                               void* stream) {
     FN_REQUIRE(stats && reps && count && beta && save_scale && save_shift && CB > 0 && (!moving_mean == !moving_var), "bn_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(CB, 256)), dim3(256), 0, (hipStream_t)stream, stats, sq_off, rep_stride, reps, count, beta,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(CB, 256)), dim3(256), 0, (hipStream_t)stream, (const acc_t*)stats, sq_off, rep_stride, reps, count, beta,
                        save_scale, save_shift, moving_mean, moving_var, momentum, eps, CB);
     return check_launch("bn_finalize");
 }
 
-extern "C" int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, int M, int C, const float* stats, int stats_sq_off,
+extern "C" int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, int M, int C, const fn_acc_t* stats, int stats_sq_off,
                                     int stats_replicas, int stats_rep_stride, const float* beta,
                                     float* save_scale, float* save_shift, float* moving_mean, float* moving_var, float momentum, float eps,
                                     int relu, int dtype, void* stream) {
@@ -820,13 +824,14 @@ extern "C" int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, 
     const int stripes = cdiv(C, 64);
     int rpb = cdiv((long)M * stripes, 2048);
     if (rpb < 32) rpb = 32;
-    LAUNCH_T(dtype, bn_relu_fwd_kernel, dim3(cdiv(M, rpb), stripes), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)y, ld_y, (unsigned short*)z, ld_z, M, C, stats, stats_sq_off, stats_replicas > 0 ? stats_replicas : 1, stats_rep_stride, beta, save_scale, save_shift, moving_mean, moving_var, momentum, eps, relu, rpb);
+    LAUNCH_T(dtype, bn_relu_fwd_kernel, dim3(cdiv(M, rpb), stripes), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)y, ld_y, (unsigned short*)z, ld_z, M, C, (const acc_t*)stats, stats_sq_off, stats_replicas > 0 ? stats_replicas : 1, stats_rep_stride, beta, save_scale, save_shift, moving_mean, moving_var, momentum, eps, relu, rpb);
     return check_launch("bn_relu_fwd");
 }
 
 extern "C" int fn_bn_relu_train_bwd(void* dz, int ld_d, const void* y, int ld_y, int M, int C, const float* beta, const float* save_scale,
-                                    const float* save_shift, float* dbeta, float* acc, int acc_sq_off, int acc_replicas, int acc_rep_stride,
+                                    const float* save_shift, float* dbeta, fn_acc_t* acc_, int acc_sq_off, int acc_replicas, int acc_rep_stride,
                                     int reduced, int relu, int dtype, void* stream) {
+    acc_t* acc = reinterpret_cast<acc_t*>(acc_);
     DT_CHECK(dtype);
     FN_REQUIRE(dz && y && beta && save_scale && save_shift && dbeta && acc && M > 0 && C > 0 && C % 8 == 0 && ld_d % 8 == 0 &&
                    ld_y % 8 == 0 && C <= 4096, "bn_bwd: bad arguments");
@@ -884,9 +889,10 @@ extern "C" int fn_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, in
     return check_launch("avgpool_bwd");
 }
 
-extern "C" int fn_residual_bwd(const void* dout, const void* out, void* dtrunk, void* dup, float* dbias, int M, int C, float scale, int relu,
+extern "C" int fn_residual_bwd(const void* dout, const void* out, void* dtrunk, void* dup, fn_acc_t* dbias_, int M, int C, float scale, int relu,
                                int accumulate, int dtype, void* stream) {
     DT_CHECK(dtype);
+    acc_t* dbias = reinterpret_cast<acc_t*>(dbias_);
     FN_REQUIRE(dout && dtrunk && dup && dbias && (out || !relu) && M > 0 && C > 0 && C % 8 == 0 && C <= 8192, "residual_bwd: bad arguments");
     const int rpb = reduce_rows_per_block(M, C);
     LAUNCH_T(dtype, residual_bwd_kernel, dim3(cdiv(M, rpb), cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dout, (const unsigned short*)out, (unsigned short*)dtrunk, (unsigned short*)dup, dbias, M, C, scale, relu, accumulate, rpb);
@@ -922,4 +928,17 @@ extern "C" int fn_cast_f32_to_lp(const float* x, void* y, long n, int dtype, voi
     FN_REQUIRE(x && y && n > 0, "cast: bad arguments");
     LAUNCH_T(dtype, cast_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)y, n);
     return check_launch("cast");
+}
+
+// fixed-point accumulators -> fp32 (bias gradients into the flat gradient buffer; fn_acc_t in facenet_hip.h)
+namespace fn {
+__global__ __launch_bounds__(256) void acc_to_float_kernel(const acc_t* __restrict__ src, float* __restrict__ dst, long n, double scale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = (float)((double)src[i] * scale);
+}
+}  // namespace fn
+extern "C" int fn_acc_to_float(const fn_acc_t* src, float* dst, long n, int bits, void* stream) {
+    FN_REQUIRE(src && dst && n > 0 && bits >= 0 && bits < 63, "acc_to_float: bad arguments");
+    hipLaunchKernelGGL(acc_to_float_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const acc_t*>(src), dst, n,
+                       1.0 / (double)(1ll << bits));
+    return check_launch("acc_to_float");
 }

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(1024) void select_rank_kernel(int T, int* __restric
 }
 
 // emb rows (a0,p0,n0,a1,...), fp32 [3T,E].  One wave per triplet.
-__global__ __launch_bounds__(256) void triplet_loss_kernel(const float* __restrict__ emb, float* __restrict__ demb, float* __restrict__ loss,
+__global__ __launch_bounds__(256) void triplet_loss_kernel(const float* __restrict__ emb, float* __restrict__ demb, acc_t* __restrict__ loss,
                                                            int T, int E, float alpha) {
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= T) return;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void triplet_loss_kernel(const float* __restri
     neg = wave_sum(neg);
     const float l = pos - neg + alpha;
     const float on = l > 0.f ? 1.f : 0.f;
-    if (lane == 0) atomicAdd(loss, fmaxf(l, 0.f) / (float)T);
+    if (lane == 0) acc_add<ACC_GRAD>(loss, fmaxf(l, 0.f) / (float)T);
     if (demb) {
         const float s = 2.f * on / (float)T;
         float* da = demb + (long)(3 * t) * E;
@@ -242,8 +242,8 @@ __global__ __launch_bounds__(256) void triplet_loss_kernel(const float* __restri
 // one workgroup per row: loss += (lse - logit[label])/N ; dlogits = (softmax - onehot) * grad_scale (low precision, padded cols = 0)
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits, int ld, const int* __restrict__ labels,
-                                                           float* __restrict__ loss, unsigned short* __restrict__ dlogits, int ld_d,
-                                                           float* __restrict__ dbias, int N, int C, float grad_scale) {
+                                                           acc_t* __restrict__ loss, unsigned short* __restrict__ dlogits, int ld_d,
+                                                           acc_t* __restrict__ dbias, int N, int C, float grad_scale) {
     __shared__ float red[4];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* x = logits + (long)row * ld;
@@ -264,7 +264,11 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
     // raises, which Trainer.set_images does on the host) and the row contributes no one-hot term
     const int lab = labels[row];
     const bool lab_ok = lab >= 0 && lab < C;
-    if (tid == 0) atomicAdd(loss, lab_ok ? (logf(s) + mx - x[lab]) / (float)N : __builtin_nanf(""));
+    // (a NaN cannot live in the fixed-point sum: an invalid label sets the flag word, loss_finish_kernel then reports NaN)
+    if (tid == 0) {
+        if (lab_ok) acc_add<ACC_GRAD>(loss, (logf(s) + mx - x[lab]) / (float)N);
+        else reinterpret_cast<volatile unsigned*>(loss)[-1] = 1u;
+    }
     if (dlogits) {
         const float inv = 1.f / s;
         unsigned short* d = dlogits + (long)row * ld_d;
@@ -272,11 +276,17 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
             float g = 0.f;
             if (c < C) {
                 g = (__expf(x[c] - mx) * inv - (c == lab ? 1.f : 0.f)) * grad_scale;
-                if (dbias) atomicAdd(&dbias[c], g);
+                if (dbias) acc_add<ACC_GRAD>(&dbias[c], g);
             }
             d[c] = LP<T>::from_f32(g);
         }
     }
+}
+
+// loss words: [0] = the loss (fp32), [1] = invalid-input flag, [2..3] = fixed-point accumulator (ACC_GRAD) the rows add into
+__global__ void loss_finish_kernel(float* loss) {
+    const float v = acc_get<ACC_GRAD>(*reinterpret_cast<const acc_t*>(loss + 2));
+    loss[0] = reinterpret_cast<const unsigned*>(loss)[1] ? __builtin_nanf("") : v;
 }
 
 }  // namespace fn
@@ -307,20 +317,26 @@ extern "C" int fn_select_triplets(const float* dist, const int32_t* labels, int 
 extern "C" int fn_triplet_loss_fwd_bwd(const float* emb, float* demb, float* loss, int T, int E, float alpha, void* stream) {
     FN_REQUIRE(emb && loss && T > 0 && E > 0, "triplet_loss: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    fill_words(loss, 0u, 0u, 1, st);
-    hipLaunchKernelGGL(triplet_loss_kernel, dim3(cdiv(T, 4)), dim3(256), 0, st, emb, demb, loss, T, E, alpha);
+    FN_REQUIRE(((uintptr_t)loss & 7) == 0, "triplet_loss: loss must be an 8-byte aligned fp32[4]");
+    fill_words(loss, 0u, 0u, 4, st);
+    hipLaunchKernelGGL(triplet_loss_kernel, dim3(cdiv(T, 4)), dim3(256), 0, st, emb, demb, reinterpret_cast<acc_t*>(loss + 2), T, E, alpha);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, loss);
     return check_launch("triplet_loss");
 }
 
-extern "C" int fn_softmax_xent_fwd_bwd(const float* logits, int ld, const int32_t* labels, float* loss, void* dlogits_lp, int ld_d, float* dbias,
+extern "C" int fn_softmax_xent_fwd_bwd(const float* logits, int ld, const int32_t* labels, float* loss, void* dlogits_lp, int ld_d, fn_acc_t* dbias_,
                                        int N, int C, float grad_scale, int dtype, void* stream) {
+    acc_t* dbias = reinterpret_cast<acc_t*>(dbias_);
+    FN_REQUIRE(((uintptr_t)loss & 7) == 0, "softmax_xent: loss must be an 8-byte aligned fp32[4]");
     FN_REQUIRE(dtype == FN_BF16 || dtype == FN_F16, "dtype %d unsupported", dtype);
     FN_REQUIRE(logits && labels && loss && N > 0 && C > 0 && ld >= C && (!dlogits_lp || ld_d >= C), "softmax_xent: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    fill_words(loss, 0u, 0u, 1, st);
+    fill_words(loss, 0u, 0u, 4, st);
+    acc_t* lacc = reinterpret_cast<acc_t*>(loss + 2);
     if (dtype == FN_BF16)
-        hipLaunchKernelGGL(softmax_xent_kernel<__bf16>, dim3(N), dim3(256), 0, st, logits, ld, labels, loss, (unsigned short*)dlogits_lp, ld_d, dbias, N, C, grad_scale);
+        hipLaunchKernelGGL(softmax_xent_kernel<__bf16>, dim3(N), dim3(256), 0, st, logits, ld, labels, lacc, (unsigned short*)dlogits_lp, ld_d, dbias, N, C, grad_scale);
     else
-        hipLaunchKernelGGL(softmax_xent_kernel<_Float16>, dim3(N), dim3(256), 0, st, logits, ld, labels, loss, (unsigned short*)dlogits_lp, ld_d, dbias, N, C, grad_scale);
+        hipLaunchKernelGGL(softmax_xent_kernel<_Float16>, dim3(N), dim3(256), 0, st, logits, ld, labels, lacc, (unsigned short*)dlogits_lp, ld_d, dbias, N, C, grad_scale);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, loss);
     return check_launch("softmax_xent");
 }

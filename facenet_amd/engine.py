@@ -243,6 +243,7 @@ class Network:
                 L.bias_off = off
                 off += L.cout
         self.n_params = (off + 3) // 4 * 4
+        self.bias_lo = self.beta_base + self.CB          # [bias_lo, n_params): the biases
         self.max_layer_elems = max(L.numel for L in self.layers.values())
 
     def _alloc_params(self, seed: int):
@@ -415,6 +416,15 @@ class Network:
                                        _ptr(self.S_mean), _ptr(self.S_var), _ptr(self.table), len(self.layers),
                                        self.max_layer_elems, BN_EPS, _lib.dtype_code(self.infer_dtype), st), "fold_bn")
 
+    def alloc_grads(self) -> torch.Tensor:
+        """The flat fp32 gradient buffer G (laid out like P) and Gacc, the fixed-point (fn_acc_t) accumulators of the bias
+        gradients: bias gradients are sums over many workgroups, added as integers (order-independent) and converted into
+        G[bias_lo:] by the plan's `grad_finalize` launch.  Both are zeroed before every backward pass."""
+        if self.G is None:
+            self.G = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+            self.Gacc = torch.zeros(max(1, self.n_params - self.bias_lo), dtype=torch.int64, device=self.device)
+        return self.G
+
     def count_variables(self) -> Tuple[int, int]:
         """(total, trainable) counted on the UN-padded Keras shapes (SURVEY.md shape table)."""
         tot = tr = 0
@@ -536,7 +546,7 @@ class Lowering:
 
     def input(self, H: int, W: int) -> Slice:
         self.images = None if self.declare else torch.zeros(self.N, H, W, 3, dtype=torch.uint8, device=self.net.device)
-        self.norm_work = None if self.declare else torch.zeros(4 * self.N, dtype=torch.float32, device=self.net.device)
+        self.norm_work = None if self.declare else torch.zeros(8 * self.N, dtype=torch.float32, device=self.net.device)
         b = self.buf("input", H, W, 8)
         return b.full()
 
@@ -714,9 +724,10 @@ class Lowering:
         CB = net.CB
         N = self.N
         if self.training:
-            # BN workspace: STAT_REPLICAS x (sum | sumsq) accumulator replicas, then s2 (backward)
-            self.ws = torch.zeros((2 * STAT_REPLICAS + 1) * CB, dtype=torch.float32, device=dev)
-            self.ws_b = torch.zeros(2 * STAT_REPLICAS * CB, dtype=torch.float32, device=dev)   # BN-backward sums (replicated)
+            # BN workspaces: STAT_REPLICAS x (sum | sumsq) accumulator replicas of fixed-point fn_acc_t (int64): integer atomics,
+            # so the totals -- and with them every training step -- have the same bits whatever order the workgroups arrive in
+            self.ws = torch.zeros(2 * STAT_REPLICAS * CB, dtype=torch.int64, device=dev)
+            self.ws_b = torch.zeros(2 * STAT_REPLICAS * CB, dtype=torch.int64, device=dev)   # BN-backward sums (replicated)
             self.save_scale = torch.zeros(CB, dtype=torch.float32, device=dev)
             self.save_shift = torch.zeros(CB, dtype=torch.float32, device=dev)
             self.head_mean = torch.zeros(net.E, dtype=torch.float32, device=dev)
@@ -955,6 +966,16 @@ class Lowering:
             r.extra.pop("rb_fused", None)
         for r in reversed(self.recs):
             getattr(self, "_bwd_" + r.kind)(r)
+        self.emit_grad_finalize(self.bwd)
+
+    def emit_grad_finalize(self, lst: List[Op]):
+        """Bias gradients leave their fixed-point accumulators (net.Gacc) for the fp32 gradient buffer: one launch at the end of
+        backward, before the optimiser / the all-reduce of the bias bucket."""
+        net = self.net
+        n = net.n_params - net.bias_lo
+        if n > 0:
+            self._emit(lst, "grad_finalize", net.lib.fn_acc_to_float, _ptr(net.Gacc), _ptr(net.G, net.bias_lo), n, 40,
+                       r=[region(net.Gacc)], w=[region(net.G, net.bias_lo, net.n_params)])
 
     def _mark(self, L: Layer):
         self.bwd_marks.append((len(self.bwd), L.index))
@@ -967,6 +988,13 @@ class Lowering:
                    _ptr(self.head_rstd), _ptr(net.G, gb), _ptr(self.head_dy), self.N, net.E, self.dt,
                    r=[region(self._demb), self._ra(r.x), region(self.head_mean), region(self.head_rstd)],
                    w=[region(self.head_dy), region(net.G, gb, gb + net.E)])
+
+    def _bias_acc(self, L: Layer) -> Tuple[int, Region]:
+        """(pointer, region) of the fixed-point accumulator that receives the bias gradient of layer L (net.Gacc mirrors the
+        bias part of the flat gradient buffer; `grad_finalize` at the end of backward converts it into G)."""
+        net = self.net
+        o = L.bias_off - net.bias_lo
+        return _ptr(net.Gacc, o), region(net.Gacc, o, o + L.cout)
 
     def _bwd_conv(self, r: Rec):
         net, lib, L = self.net, self.net.lib, r.layer
@@ -982,9 +1010,10 @@ class Lowering:
                 dup = torch.zeros(y.buf.M, y.buf.C, dtype=self.dtype, device=net.device)
                 self._dup[L.name] = dup
                 acc = self._grad_mode(t)
+                bptr, breg = self._bias_acc(L)
                 self._emit(self.bwd, "residual_bwd:" + L.name, lib.fn_residual_bwd, _ptr(y.buf.grad), _ptr(y.buf.act), _ptr(t.buf.grad),
-                           _ptr(dup), _ptr(net.G, L.bias_off), y.buf.M, y.buf.C, r.extra["scale"], 1 if r.extra["relu"] else 0, acc, self.dt,
-                           r=[self._rg(y), self._ra(y)], w=[self._rg(t), region(dup), region(net.G, L.bias_off, L.bias_off + L.cout)])
+                           _ptr(dup), bptr, y.buf.M, y.buf.C, r.extra["scale"], 1 if r.extra["relu"] else 0, acc, self.dt,
+                           r=[self._rg(y), self._ra(y)], w=[self._rg(t), region(dup), breg])
             dy_ptr, ld_dy, dy_reg = _ptr(dup), y.buf.C, region(dup)
         elif kind == "f32":
             dy_ptr, ld_dy, dy_reg = _ptr(self.head_dy), net.E, region(self.head_dy)
@@ -1069,10 +1098,10 @@ class Lowering:
         g.rb_dtrunk = _ptr(t.buf.grad)
         g.rb_accumulate = self._grad_mode(t)
         g.rb_dup = _ptr(dup)
-        g.rb_dbias = _ptr(net.G, Lp.bias_off)
+        g.rb_dbias, breg = self._bias_acc(Lp)
         g.rb_scale = float(prev.extra["scale"])
         rd += [self._rg(x), self._ra(x)]
-        wr[:] = [self._rg(t), region(dup), region(net.G, Lp.bias_off, Lp.bias_off + Lp.cout)]
+        wr[:] = [self._rg(t), region(dup), breg]
 
     def _bwd_bn(self, r: Rec):
         net = self.net

@@ -265,15 +265,13 @@ class Trainer:
         self.n_streams = n_streams
         dev, E, lib = net.device, net.E, net.lib
         self.lib = lib
-        if net.G is None:
-            net.G = torch.zeros(net.n_params, dtype=torch.float32, device=dev)
-        self.G = net.G
+        self.G = net.alloc_grads()       # + net.Gacc: fixed-point accumulators of the bias gradients (engine.Network.alloc_grads)
         self.M = torch.zeros_like(self.G)
         self.V = torch.zeros_like(self.G)
         # hyper = {lr, beta1^t, beta2^t, grad_scale, t (int32 bits), 3 spare words}; lives on device so HIP-graph replays see
         # LR changes and advance Adam's step count themselves (fn_adam_tick)
         self.hyper = torch.tensor([lr, 1.0, 1.0, 1.0 / world_size, 0.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
-        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros(4, dtype=torch.float32, device=dev)     # [0] the loss; [1..3] the launch's flag + fixed-point accumulator
         if world_size > 1:
             # MirroredStrategy creates every replica from the SAME variables (apps/train_softmax_tf2_gpus.py:49-67): rank 0's
             # parameters and moving statistics win, whatever seed or file the other ranks were built from
@@ -288,7 +286,7 @@ class Trainer:
         r_emb = region(emb)
         self.emb = emb.view(batch, E)
         self.pre_ops: List[Op] = [
-            Op("zero_grads", torch_op(lambda: self.G.zero_()), (), writes=(region(self.G),)),
+            Op("zero_grads", torch_op(lambda: (self.G.zero_(), net.Gacc.zero_())), (), writes=(region(self.G), region(net.Gacc))),
             Op("zero_bn_workspace", torch_op(lambda: (self.plan.ws.zero_(), self.plan.ws_b.zero_())), (),
                writes=(region(self.plan.ws), (self.plan.ws.data_ptr() + 1, 0, net.CB), region(self.plan.ws_b),
                        (self.plan.ws_b.data_ptr() + 1, 0, net.CB))),
@@ -313,7 +311,7 @@ class Trainer:
             rw = region(net.W_train, L.w_off, L.w_off + L.numel)
             rwt = region(net.Wt_train, L.w_off, L.w_off + L.numel)
             rgw = region(self.G, L.w_off, L.w_off + L.numel)
-            rgb = region(self.G, L.bias_off, L.bias_off + L.cout)
+            rgb = region(net.Gacc, L.bias_off - net.bias_lo, L.bias_off - net.bias_lo + L.cout)
             d = self._cls_desc(L)
             d.x, d.w, d.y, d.bias, d.out_f32 = _ptr(self.emb_lp), _ptr(net.W_train, L.w_off), _ptr(self.logits), _ptr(net.P, L.bias_off), 1
             self._op(self.loss_ops, "cast_emb", lib.fn_cast_f32_to_lp, _ptr(emb), _ptr(self.emb_lp), batch * E, self.dt,
@@ -321,7 +319,7 @@ class Trainer:
             self._op(self.loss_ops, "conv_fwd:classifier", lib.fn_conv2d_fwd, C.byref(d), keep=(d,),
                      r=[region(self.emb_lp), rw, region(net.P, L.bias_off, L.bias_off + L.cout)], w=[region(self.logits)])
             self._op(self.loss_ops, "softmax_xent", lib.fn_softmax_xent_fwd_bwd, _ptr(self.logits), Cp, _ptr(self.labels), _ptr(self.loss),
-                     _ptr(self.dlogits), Cp, _ptr(self.G, L.bias_off), batch, Cr, 1.0 / batch, self.dt,
+                     _ptr(self.dlogits), Cp, _ptr(net.Gacc, L.bias_off - net.bias_lo), batch, Cr, 1.0 / batch, self.dt,
                      r=[region(self.logits), region(self.labels)], w=[region(self.loss), region(self.dlogits), rgb])
             w = self._cls_desc(L)
             w.x, w.y, w.dw = _ptr(self.emb_lp), _ptr(self.dlogits), _ptr(self.G, L.w_off)
@@ -423,6 +421,7 @@ class Trainer:
     # ---- one step ------------------------------------------------------------------------------
     def _zero(self):
         self.G.zero_()
+        self.net.Gacc.zero_()
         self.plan.ws.zero_()
         self.plan.ws_b.zero_()
 
@@ -623,7 +622,7 @@ class Trainer:
         self.hyper[0:1].fill_(float(lr))     # device write: visible to the next graph replay
 
     def loss_value(self) -> float:
-        return float(self.loss.item())
+        return float(self.loss[0].item())
 
 
 class TripletMiner:

@@ -40,7 +40,7 @@ def triplet_loss(emb: torch.Tensor, alpha: float, with_grad: bool = False):
     lib = _lib.load()
     e = emb.to(dtype=torch.float32).contiguous()
     T, E = e.shape[0] // 3, e.shape[1]
-    loss = torch.zeros(1, dtype=torch.float32, device=e.device)
+    loss = torch.zeros(4, dtype=torch.float32, device=e.device)      # word 0 = the loss, words 1-3 = the launch's accumulator
     grad = torch.empty_like(e) if with_grad else None
     _lib.check(lib.fn_triplet_loss_fwd_bwd(_ptr(e), _ptr(grad) if with_grad else None, _ptr(loss), T, E, float(alpha),
                                            torch.cuda.current_stream(e.device).cuda_stream), "triplet_loss")

@@ -23,6 +23,16 @@ extern "C" {
 #define FN_BF16 0
 #define FN_F16 1
 
+/* Order-independent accumulators.  Sums that many workgroups contribute to -- BatchNorm batch statistics, the BatchNorm-backward
+ * sums, bias gradients, the losses -- are 64-bit FIXED-POINT integers: every workgroup converts its fp32 partial sum once (round
+ * to nearest) and adds it with an integer atomic, so the total has the same bits whatever order the workgroups arrive in and a
+ * training step is reproducible bit for bit (fp32 atomics were not).  value = integer * 2^-bits.  Forward statistics use
+ * FN_ACC_STAT_BITS (|sum| < 8.8e12), gradient sums FN_ACC_GRAD_BITS (|sum| < 8.4e6, resolution 9e-13).  Callers zero them
+ * (all-zero bits) and read them back with fn_acc_to_float or by scaling on the host. */
+typedef int64_t fn_acc_t;
+#define FN_ACC_STAT_BITS 20
+#define FN_ACC_GRAD_BITS 40
+
 const char* fn_last_error(void);
 int fn_abi_version(void);
 
@@ -54,7 +64,7 @@ typedef struct fn_conv_desc {
     void* dx;                  /* dgrad: output dX [N,H,W,ld_x] */
     float* dw;                 /* wgrad: fp32 [Cout][KH*KW*Cin], atomically accumulated (caller zeroes) */
     const float* bias;         /* fwd: per-Cout fp32 or NULL (BN-folded shift / `up` bias) */
-    float* stats;              /* fwd: NULL or fp32: stats[c] += sum, stats[stats_sq_off + c] += sum of squares (BN batch statistics) */
+    fn_acc_t* stats;           /* fwd: NULL or fixed point (FN_ACC_STAT_BITS): stats[c] += sum, stats[stats_sq_off + c] += sum of squares (BN batch statistics) */
     const void* resid;         /* fwd: residual trunk [N,OH,OW,ld_res] or NULL */
     /* dgrad: optional fused reduction of the BatchNorm backward of the layer that produced x (see fn_bn_relu_train_bwd):
      * bn_y = that layer's raw output (same slice as dx), bn_acc[rep*stride + c] += sum dyh, [.. + bn_sq_off + c] += sum dyh*xhat */
@@ -62,7 +72,7 @@ typedef struct fn_conv_desc {
     const float* bn_scale;
     const float* bn_shift;
     const float* bn_beta;
-    float* bn_acc;
+    fn_acc_t* bn_acc;          /* fixed point, FN_ACC_GRAD_BITS */
     int32_t ld_bn_y, bn_sq_off, bn_replicas, bn_rep_stride, bn_relu;
     /* fwd / wgrad: "normalise on load".  When nrm_stats is set, x is the RAW output of a BatchNormalization(center only)+ReLU
      * layer whose batch statistics (sum | sum of squares, replicated like `stats`) have been accumulated by the producing
@@ -70,7 +80,7 @@ typedef struct fn_conv_desc {
      * is staged (zero padding stays zero).  The activated tensor is then never written.  Index 0 of nrm_stats / nrm_beta
      * is channel 0 of x; nrm_count = N*H*W of x.  Cin <= 512.  fn_bn_finalize publishes the same scale / shift for the
      * backward pass and updates the moving statistics. */
-    const float* nrm_stats;
+    const fn_acc_t* nrm_stats; /* as `stats` */
     const float* nrm_beta;
     int32_t nrm_sq_off, nrm_replicas, nrm_rep_stride, nrm_count;
     float nrm_eps;
@@ -105,7 +115,7 @@ typedef struct fn_conv_desc {
     const void* rb_out;
     void* rb_dtrunk;
     void* rb_dup;
-    float* rb_dbias;
+    fn_acc_t* rb_dbias;        /* fixed point, FN_ACC_GRAD_BITS (fn_acc_to_float moves the bias gradients into the fp32 gradient buffer) */
     float rb_scale;
     int32_t rb_accumulate;
     /* fwd, optional: PReLU with one slope per output channel (Keras PReLU(shared_axes=[1,2]) after Conv2D, PReLU() after Dense:
@@ -158,7 +168,7 @@ int fn_conv2d_variant(const fn_conv_desc* d, int op);
 
 /* ---- input normalisation: facenet/facenet.py:67-86 (ImageProcessing.call) -------
  * u8 NHWC [N,H,W,3] -> low precision [N,H,W,8] (channels 3..7 zero), mode 0 = per-image
- * min/max to [-1,1], mode 1 = per_image_standardization.  `work` = fp32 [4*N] scratch. */
+ * min/max to [-1,1], mode 1 = per_image_standardization.  `work` = 8*N 32-bit words of scratch (8-byte aligned). */
 int fn_image_normalize(const uint8_t* img, void* out, float* work, int N, int HW, int mode, int dtype, void* stream);
 int fn_image_normalize_f32(const float* img, void* out, float* work, int N, int HW, int mode, int dtype, void* stream);
 /* tf.image.resize(images, [size,size]) of facenet.py:70 (bilinear, half-pixel centres, no antialias): u8 or fp32 NHWC
@@ -175,7 +185,7 @@ int fn_gather_images(const uint8_t* pool, const int32_t* idx, uint8_t* out, int 
 /* Batched finalisation for the layers consumed through nrm_* (no fn_bn_relu_train_fwd launch): for every channel c < CB with
  * reps[c] > 0: mean/var from the replicated sums (count[c] elements), save_scale = rstd, save_shift = beta - mean*rstd,
  * moving statistics updated as in fn_bn_relu_train_fwd.  One launch for the whole network. */
-int fn_bn_finalize(const float* stats, int sq_off, int rep_stride, const int32_t* reps, const int32_t* count, const float* beta,
+int fn_bn_finalize(const fn_acc_t* stats, int sq_off, int rep_stride, const int32_t* reps, const int32_t* count, const float* beta,
                    float* save_scale, float* save_shift, float* moving_mean, float* moving_var, float momentum, float eps, int CB,
                    void* stream);
 
@@ -184,7 +194,7 @@ int fn_bn_finalize(const float* stats, int sq_off, int rep_stride, const int32_t
  * Training: y (raw conv output, channel slice [0,C) of a [M,ld_y] buffer) -> z = relu((y-mean)*rstd+beta)
  * with batch statistics from `stats` (sum,sumsq as written by fn_conv2d_fwd); scale=rstd and
  * shift=beta-mean*rstd are saved for backward and the moving statistics are updated (biased variance). */
-int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, int M, int C, const float* stats, int stats_sq_off, int stats_replicas,
+int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, int M, int C, const fn_acc_t* stats, int stats_sq_off, int stats_replicas,
                          int stats_rep_stride, const float* beta,
                          float* save_scale, float* save_shift, float* moving_mean, float* moving_var, float momentum, float eps,
                          int relu, int dtype, void* stream);
@@ -194,7 +204,7 @@ int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, int M, int 
  * with reduced = 0 this call fills it (reduce kernel, replica 0), with reduced = 1 a fn_conv2d_dgrad epilogue already did.
  * dbeta[C] += sum dyh. */
 int fn_bn_relu_train_bwd(void* dz, int ld_d, const void* y, int ld_y, int M, int C, const float* beta, const float* save_scale,
-                         const float* save_shift, float* dbeta, float* acc, int acc_sq_off, int acc_replicas, int acc_rep_stride,
+                         const float* save_shift, float* dbeta, fn_acc_t* acc, int acc_sq_off, int acc_replicas, int acc_rep_stride,
                          int reduced, int relu, int dtype, void* stream);
 
 /* ---- pooling: MaxPool2D(3, strides=2, 'valid') :301,369,409 ; AvgPool2D([3,3]) + Flatten :460-461 */
@@ -243,8 +253,11 @@ int fn_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype, vo
 
 /* ---- residual backward for "net = act(net + scale*up)" (:145-148,199-202,254-257) ------------
  * dpre = dout * (out>0 if relu); dtrunk = dpre (or += when accumulate); dup = scale*dpre; dbias[C] += sum(dup). */
-int fn_residual_bwd(const void* dout, const void* out, void* dtrunk, void* dup, float* dbias, int M, int C, float scale, int relu,
+int fn_residual_bwd(const void* dout, const void* out, void* dtrunk, void* dup, fn_acc_t* dbias, int M, int C, float scale, int relu,
                     int accumulate, int dtype, void* stream);
+
+/* dst[i] = src[i] * 2^-bits (the bias gradients leave their fixed-point accumulators for the fp32 gradient buffer) */
+int fn_acc_to_float(const fn_acc_t* src, float* dst, long n, int bits, void* stream);
 
 /* ---- embedding head on fp32 [N,E]: BN without ReLU (:467) and tf.nn.l2_normalize (:491-492) ---- */
 int fn_head_bn_fwd(const float* y, float* out, int N, int E, const float* beta, float* moving_mean, float* moving_var,
@@ -263,6 +276,7 @@ int fn_cast_f32_to_lp(const float* x, void* y, long n, int dtype, void* stream);
 int fn_pairwise_sqdist(const float* xa, const float* xb, float* out, float* range, int n, int m, int E, int metric, void* stream);
 int fn_select_triplets(const float* dist, const int32_t* labels, int n, float alpha, int nrof_triplets, uint32_t seed,
                        int semi_hard, int32_t* triplets, int32_t* info, void* stream);
+/* loss: fp32[4] -- word 0 receives the loss; words 2-3 are the launch's own fixed-point accumulator (FN_ACC_GRAD_BITS) */
 int fn_triplet_loss_fwd_bwd(const float* emb, float* demb, float* loss, int T, int E, float alpha, void* stream);
 
 /* ---- face-to-face validation statistics: facenet/statistics.py:111-138 (ConfidenceMatrix) with the class-balanced
@@ -272,8 +286,9 @@ int fn_triplet_loss_fwd_bwd(const float* emb, float* demb, float* loss, int T, i
 int fn_confidence_counts(const float* emb, const int32_t* cls_start, int C, int E, const float* thresholds, int T, int metric,
                          double* out, int32_t* range, void* stream);
 
-/* ---- softmax classifier loss: apps/train_softmax.py:91 (SparseCategoricalCrossentropy(from_logits)) */
-int fn_softmax_xent_fwd_bwd(const float* logits, int ld, const int32_t* labels, float* loss, void* dlogits_lp, int ld_d, float* dbias, int N,
+/* ---- softmax classifier loss: apps/train_softmax.py:91 (SparseCategoricalCrossentropy(from_logits)); loss: fp32[4] as above;
+ * dbias (optional): fixed point, FN_ACC_GRAD_BITS, += column sums of dlogits */
+int fn_softmax_xent_fwd_bwd(const float* logits, int ld, const int32_t* labels, float* loss, void* dlogits_lp, int ld_d, fn_acc_t* dbias, int N,
                             int C, float grad_scale, int dtype, void* stream);
 
 /* ---- optimiser: tf.keras.optimizers.Adam(epsilon=0.1) apps/train_softmax.py:92 + Keras L2(5e-4) (:65) ----

@@ -56,7 +56,7 @@ def test_block_forward_backward_against_rounded_autograd(kind, H, W, C, N, scale
     net.load_keras_params(params)
     trainable = [k for k in params if not k.endswith(("/moving_mean", "/moving_variance"))]
     plan = net.plan(N, training=True)
-    net.G = torch.zeros(net.n_params, dtype=torch.float32, device=net.device)
+    net.alloc_grads()
     # the trunk is the output of a ReLU in the real network: non-negative, O(1)
     x = torch.relu(torch.randn(N, H, W, C, generator=g) + 0.3).to(dt)
     trunk, out = plan.bufs["trunk"], plan.embedding.buf
@@ -136,7 +136,7 @@ def test_batchnorm_statistics_with_mean_far_from_zero(dt, lib):
     y = torch.zeros(M, Cc, dtype=dt, device=dev)
     z = torch.zeros(M, Cc, dtype=dt, device=dev)
     reps = 16
-    ws = torch.zeros(reps * 2 * Cc, dtype=torch.float32, device=dev)
+    ws = torch.zeros(reps * 2 * Cc, dtype=torch.int64, device=dev)          # fixed-point accumulators (fn_acc_t)
     d = conv_desc(N, H, W, Cc, Cc, 1, 1, 1, 0, 0, code)
     d.x, d.w, d.y = ptr(xd), ptr(wd), ptr(y)
     d.stats, d.stats_sq_off, d.stats_replicas, d.stats_rep_stride = ptr(ws), Cc, reps, 2 * Cc

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from facenet_amd import _lib
-from tests.util import conv_desc, lp_dtype, ptr, ref_conv, rel_err, stream
+from tests.util import ACC_GRAD_BITS, ACC_STAT_BITS, conv_desc, from_acc, lp_dtype, ptr, ref_conv, rel_err, stream, to_acc
 
 pytestmark = pytest.mark.gpu
 
@@ -85,11 +85,17 @@ def test_conv_fwd(lib, case, dt):
     d = _halo(conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt), case)
     y = torch.full((N, d.OH, d.OW, Cout), 7.0, dtype=lp_dtype(dt), device="cuda")
     reps = 4
-    stats_r = torch.zeros(reps, 2 * Cout, dtype=torch.float32, device="cuda")
+    stats_r = torch.zeros(reps, 2 * Cout, dtype=torch.int64, device="cuda")      # fixed-point accumulators (fn_acc_t)
     d.x, d.w, d.y, d.stats, d.stats_sq_off, d.stats_replicas, d.stats_rep_stride = ptr(x), ptr(w), ptr(y), ptr(stats_r), Cout, reps, 2 * Cout
     _lib.check(lib.fn_conv2d_fwd(C.byref(d), stream()))
     torch.cuda.synchronize()
-    stats = stats_r.sum(0)            # row tiles are spread over the accumulator replicas
+    stats = from_acc(stats_r.sum(0), ACC_STAT_BITS)            # row tiles are spread over the accumulator replicas
+    first = stats_r.clone()
+    for _ in range(2):                 # integer accumulation: the statistics have the same bits every run, in every replica
+        stats_r.zero_()
+        _lib.check(lib.fn_conv2d_fwd(C.byref(d), stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(stats_r, first)
     ref = ref_conv(x, w, s, ph, pw)
     assert rel_err(y, ref) < (6e-3 if dt == _lib.FN_BF16 else 8e-4)
     # BatchNorm statistics come from the fp32 accumulators
@@ -334,7 +340,7 @@ def test_dgrad_fused_bn_backward_reduction(lib, dt, H):
     sc = torch.rsqrt(var + 1e-3).contiguous()
     sh = (beta - mean * sc).contiguous()
     reps = 4
-    acc = torch.zeros(reps, 2 * Cin, device="cuda")
+    acc = torch.zeros(reps, 2 * Cin, dtype=torch.int64, device="cuda")      # fixed point, FN_ACC_GRAD_BITS
     dx = torch.zeros(N, H, W, Cin, dtype=lp_dtype(dt), device="cuda")
     d.y, d.w, d.dx = ptr(dy), ptr(wt), ptr(dx)
     d.bn_y, d.ld_bn_y, d.bn_scale, d.bn_shift, d.bn_beta = ptr(yraw), Cin, ptr(sc), ptr(sh), ptr(beta)
@@ -342,7 +348,7 @@ def test_dgrad_fused_bn_backward_reduction(lib, dt, H):
     assert (lib.fn_conv2d_variant(C.byref(d), 1) >= 9000000) == (H == 37)
     _lib.check(lib.fn_conv2d_dgrad(C.byref(d), stream()))
     # reference: standalone reduce on the (rounded) dx
-    acc_ref = torch.zeros(2 * Cin, device="cuda")
+    acc_ref = torch.zeros(2 * Cin, dtype=torch.int64, device="cuda")
     dbeta_ref = torch.zeros(Cin, device="cuda")
     dx_ref = dx.clone()
     _lib.check(lib.fn_bn_relu_train_bwd(ptr(dx_ref), Cin, ptr(yraw), Cin, M, Cin, ptr(beta), ptr(sc), ptr(sh), ptr(dbeta_ref), ptr(acc_ref), Cin, 1, 0,
@@ -352,7 +358,7 @@ def test_dgrad_fused_bn_backward_reduction(lib, dt, H):
                                         1, 1, dt, stream()))
     torch.cuda.synchronize()
     tol = 2e-2 if dt == _lib.FN_BF16 else 3e-3       # fused sums use the un-rounded fp32 gradient
-    assert rel_err(acc.sum(0), acc_ref) < tol
+    assert rel_err(from_acc(acc.sum(0), ACC_GRAD_BITS), from_acc(acc_ref, ACC_GRAD_BITS)) < tol
     assert rel_err(dbeta, dbeta_ref) < tol
     assert rel_err(dx, dx_ref) < tol
 
@@ -371,11 +377,11 @@ def test_conv_normalise_on_load_equals_materialised_bn(lib, case, dt):
     raw = _mk((N, H, W, ld), dt, 1.5, seed=11)
     rawf = raw[..., 8:8 + Cin].float().reshape(M, Cin)
     reps, CBs = 4, Cin + 24                            # statistics live at offset 16 of a wider channel space
-    stats = torch.zeros(reps, 2 * CBs, dtype=torch.float32, device="cuda")
+    stats = torch.zeros(reps, 2 * CBs, dtype=torch.int64, device="cuda")
     part = torch.arange(M, device="cuda") % reps
-    for r in range(reps):                              # replicas hold partial sums, as the producing conv leaves them
-        stats[r, 16:16 + Cin] = rawf[part == r].sum(0)
-        stats[r, CBs + 16:CBs + 16 + Cin] = (rawf[part == r] ** 2).sum(0)
+    for r in range(reps):                              # replicas hold partial sums (fixed point), as the producing conv leaves them
+        stats[r, 16:16 + Cin] = to_acc(rawf[part == r].sum(0), ACC_STAT_BITS)
+        stats[r, CBs + 16:CBs + 16 + Cin] = to_acc((rawf[part == r] ** 2).sum(0), ACC_STAT_BITS)
     beta = (torch.randn(CBs, generator=torch.Generator().manual_seed(5)) * 0.3).cuda()
     z = torch.zeros_like(raw)
     sc, sh = torch.zeros(CBs, device="cuda"), torch.zeros(CBs, device="cuda")
@@ -424,7 +430,7 @@ def test_conv_normalise_on_load_rejects_wide_inputs(lib):
     x = torch.zeros(1, 3, 3, 1792, dtype=torch.bfloat16, device="cuda")
     w = torch.zeros(128, 1, 1, 1792, dtype=torch.bfloat16, device="cuda")
     y = torch.zeros(1, 3, 3, 128, dtype=torch.bfloat16, device="cuda")
-    st = torch.zeros(2 * 1792, device="cuda")
+    st = torch.zeros(2 * 1792, dtype=torch.int64, device="cuda")
     d.x, d.w, d.y, d.nrm_stats, d.nrm_beta, d.nrm_count, d.nrm_eps, d.nrm_sq_off = ptr(x), ptr(w), ptr(y), ptr(st), ptr(st), 9, 1e-3, 1792
     with pytest.raises(ValueError):
         _lib.check(lib.fn_conv2d_fwd(C.byref(d), stream()))

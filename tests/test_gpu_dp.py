@@ -61,7 +61,10 @@ def test_two_replicas_match_manual_gradient_average(use_graph):
     # replicas: identical summed gradients, identical parameters (bitwise)
     assert np.array_equal(res[0][2], res[1][2])
     assert np.array_equal(res[0][1], res[1][1])
-    # single-process emulation: two replicas' backward passes, gradients averaged by hand, one optimiser step
+    # single-process emulation: the two replicas' forward / backward passes one after the other (the launches a world-1 trainer
+    # issues, optimiser left out), gradients summed by hand, one optimiser step on their mean.  Every accumulation is order
+    # independent (fixed-point statistics and bias gradients, slab-reduced weight gradients), so the data-parallel step must
+    # reproduce this BIT FOR BIT: summed gradients and parameters.
     from facenet_amd.engine import Network
     from facenet_amd.train import Trainer
     from oracle import facenet_oracle as fo
@@ -73,40 +76,17 @@ def test_two_replicas_match_manual_gradient_average(use_graph):
         net.load_keras_params(params)
         tr = Trainer(net, batch=6, loss="triplet", alpha=0.2, lr=0.01)
         tr.set_images(torch.from_numpy(structured_images(6, seed=20 + r)))
-        st = net.stream()
-        for ops in (tr.pre_ops, tr.plan.fwd, tr.loss_ops, tr.plan.bwd):
-            tr.plan.run_ops(ops, st)
+        tr.plan.run_ops([op for op in tr.step_ops if op.name not in ("adam_tick", "adam_keras", "pack_transpose")], net.stream())
         torch.cuda.synchronize()
         grads.append(tr.G.clone())
     p0 = net.P.clone()
-    tr.G.copy_((grads[0] + grads[1]) / world)
+    gsum = grads[0] + grads[1]
+    tr.G.copy_(gsum / world)                     # the fused optimiser applies 1/world to the all-reduced SUM: the same product
     tr.plan.run_ops(tr.opt_ops, net.stream())
     torch.cuda.synchronize()
-    upd_ref = (net.P - p0).cpu().numpy()
-    upd_dp = res[0][1] - p0.cpu().numpy()
-    gsum = (grads[0] + grads[1]).cpu().numpy()
-    cos_g = float(np.dot(gsum, res[0][2]) / (np.linalg.norm(gsum) * np.linalg.norm(res[0][2])))
-    cos_u = float(np.dot(upd_ref, upd_dp) / (np.linalg.norm(upd_ref) * np.linalg.norm(upd_dp)))
-    print(f"graph={use_graph}: cosine(summed grads) {cos_g:.4f}, cosine(param update) {cos_u:.4f}, |update| {np.linalg.norm(upd_dp):.4f} vs {np.linalg.norm(upd_ref):.4f}")
-    # noise floor: the single-process emulation repeated -- fp32 atomics make two runs of the SAME step differ (DESIGN.md
-    # section 4); the data-parallel result may sit no further from the emulation than 3x that run-to-run distance
-    grads2 = []
-    for r in range(world):
-        net2 = Network(embedding_size=128, device="cuda:0", train_dtype=torch.float16)
-        net2.load_keras_params(params)
-        tr2 = Trainer(net2, batch=6, loss="triplet", alpha=0.2, lr=0.01)
-        tr2.set_images(torch.from_numpy(structured_images(6, seed=20 + r)))
-        for ops in (tr2.pre_ops, tr2.plan.fwd, tr2.loss_ops, tr2.plan.bwd):
-            tr2.plan.run_ops(ops, net2.stream())
-        torch.cuda.synchronize()
-        grads2.append(tr2.G.clone())
-    gsum2 = (grads2[0] + grads2[1]).cpu().numpy()
-    floor = float(np.linalg.norm(gsum - gsum2) / np.linalg.norm(gsum))
-    dist_dp = float(np.linalg.norm(res[0][2] - gsum) / np.linalg.norm(gsum))
-    print(f"  relative distance DP vs emulation {dist_dp:.4f}; run-to-run noise floor {floor:.4f}")
-    assert dist_dp <= 3.0 * floor + 1e-3
-    assert cos_g > 0.97 and cos_u > 0.97
-    assert abs(np.linalg.norm(upd_dp) / np.linalg.norm(upd_ref) - 1) < 0.05
+    assert float(gsum.abs().max()) > 0 and float((net.P - p0).abs().max()) > 0
+    assert np.array_equal(res[0][2], gsum.cpu().numpy())          # all-reduced gradients == hand-summed gradients, bitwise
+    assert np.array_equal(res[0][1], net.P.cpu().numpy())         # and so are the parameters after the step
 
 
 def _rank_softmax(rank, world, port, q):

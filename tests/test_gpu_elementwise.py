@@ -8,7 +8,7 @@ import torch.nn.functional as F
 
 from facenet_amd import _lib
 from oracle import facenet_oracle as fo
-from tests.util import lp_dtype, ptr, rel_err, stream
+from tests.util import ACC_GRAD_BITS, ACC_STAT_BITS, from_acc, to_acc, lp_dtype, ptr, rel_err, stream
 
 pytestmark = pytest.mark.gpu
 BF, HF = _lib.FN_BF16, _lib.FN_F16
@@ -26,7 +26,7 @@ def test_image_normalize(lib, mode):
     x[1] = 77                       # constant image: range clamps to eps (facenet.py:76)
     xt = torch.from_numpy(x).cuda()
     out = torch.zeros(3, 160, 160, 8, dtype=torch.float16, device="cuda")
-    work = torch.zeros(12, dtype=torch.float32, device="cuda")
+    work = torch.zeros(24, dtype=torch.float32, device="cuda")      # 8 words per image
     _lib.check(lib.fn_image_normalize(ptr(xt), ptr(out), ptr(work), 3, 160 * 160, mode, HF, stream()))
     ref = fo.image_processing(x, normalization=mode)
     assert torch.allclose(out[..., :3].float().cpu(), ref, atol=2e-3, rtol=2e-3)
@@ -48,7 +48,7 @@ def test_bn_relu_train_fwd_bwd(lib, dt, shape):
     y = ybuf[:, c0:c0 + Cc]
     beta = (torch.randn(Cc, generator=torch.Generator().manual_seed(2)) * 0.3).cuda()
     yf = y.float()
-    stats = torch.cat([yf.sum(0), (yf * yf).sum(0)]).contiguous()
+    stats = to_acc(torch.cat([yf.sum(0), (yf * yf).sum(0)]), ACC_STAT_BITS).contiguous()     # fixed-point accumulators (fn_acc_t)
     z = torch.zeros(M, ld, dtype=lp_dtype(dt), device="cuda")
     sc, sh = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
     mm, mv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
@@ -64,7 +64,7 @@ def test_bn_relu_train_fwd_bwd(lib, dt, shape):
     dzb = _rand((M, ld), dt, seed=3)
     dref_in = dzb[:, c0:c0 + Cc].float().cpu()
     zr.backward(dref_in)
-    dbeta, acc = torch.zeros(Cc, device="cuda"), torch.zeros(2 * Cc, device="cuda")
+    dbeta, acc = torch.zeros(Cc, device="cuda"), torch.zeros(2 * Cc, dtype=torch.int64, device="cuda")
     _lib.check(lib.fn_bn_relu_train_bwd(ptr(dzb, c0), ld, ptr(ybuf, c0), ld, M, Cc, ptr(beta), ptr(sc), ptr(sh), ptr(dbeta), ptr(acc), Cc, 1, 0,
                                         0, 1, dt, stream()))
     torch.cuda.synchronize()
@@ -118,13 +118,19 @@ def test_avgpool_and_residual_bwd(lib, dt):
     dout = _rand((M, 256), dt, seed=10)
     dtrunk = torch.zeros_like(dout)
     dup = torch.zeros_like(dout)
-    dbias = torch.zeros(256, device="cuda")
+    dbias = torch.zeros(256, dtype=torch.int64, device="cuda")        # fixed point, FN_ACC_GRAD_BITS
     _lib.check(lib.fn_residual_bwd(ptr(dout), ptr(out), ptr(dtrunk), ptr(dup), ptr(dbias), M, 256, 0.17, 1, 0, dt, stream()))
     torch.cuda.synchronize()
     dpre = dout.float() * (out.float() > 0)
     assert torch.equal(dtrunk.float(), dpre)
     assert rel_err(dup, 0.17 * dpre) < (4e-3 if dt == BF else 5e-4)
-    assert torch.allclose(dbias.cpu(), (0.17 * dpre).sum(0).cpu(), rtol=2e-3, atol=2e-3)
+    assert torch.allclose(from_acc(dbias, ACC_GRAD_BITS).cpu(), (0.17 * dpre).sum(0).cpu(), rtol=2e-3, atol=2e-3)
+    first = dbias.clone()                                    # integer accumulation: the same bits every run
+    for _ in range(3):
+        dbias.zero_()
+        _lib.check(lib.fn_residual_bwd(ptr(dout), ptr(out), ptr(dtrunk), ptr(dup), ptr(dbias), M, 256, 0.17, 1, 0, dt, stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(dbias, first)
 
 
 def test_head_bn_and_l2norm(lib):
@@ -159,26 +165,30 @@ def test_head_bn_and_l2norm(lib):
 def test_triplet_loss_and_softmax(lib):
     T, E = 7, 128
     emb = fo.l2_normalize(_rand((3 * T, E), seed=14).cpu()).cuda().contiguous()
-    demb, loss = torch.zeros_like(emb), torch.zeros(1, device="cuda")
+    demb, loss = torch.zeros_like(emb), torch.zeros(4, device="cuda")      # loss: fp32[4], word 0 = the loss
     _lib.check(lib.fn_triplet_loss_fwd_bwd(ptr(emb), ptr(demb), ptr(loss), T, E, 0.2, stream()))
     er = emb.cpu().clone().requires_grad_(True)
     lr = fo.triplet_loss(er, 0.2)
     lr.backward()
-    assert abs(loss.item() - lr.item()) < 1e-6
+    assert abs(loss[0].item() - lr.item()) < 1e-6
     assert torch.allclose(demb.cpu(), er.grad, atol=1e-6)
     # softmax cross-entropy, ragged class count with padded columns
     N, Cr, Cp = 6, 37, 40
     logits = _rand((N, Cp), seed=15, scale=3.0)
     labels = torch.tensor([0, 36, 5, 5, 17, 3], dtype=torch.int32, device="cuda")
     dl = torch.ones(N, Cp, dtype=torch.bfloat16, device="cuda")
-    dbias = torch.zeros(Cp, device="cuda")
+    dbias = torch.zeros(Cp, dtype=torch.int64, device="cuda")             # fixed point, FN_ACC_GRAD_BITS
     _lib.check(lib.fn_softmax_xent_fwd_bwd(ptr(logits), Cp, ptr(labels), ptr(loss), ptr(dl), Cp, ptr(dbias), N, Cr, 1.0 / N, BF, stream()))
     lg = logits[:, :Cr].cpu().clone().requires_grad_(True)
     ref = fo.softmax_cross_entropy(lg, labels.cpu())
     ref.backward()
-    assert abs(loss.item() - ref.item()) < 1e-5
+    assert abs(loss[0].item() - ref.item()) < 1e-5
     assert rel_err(dl[:, :Cr], lg.grad) < 5e-3 and float(dl[:, Cr:].abs().max()) == 0
-    assert torch.allclose(dbias[:Cr].cpu(), lg.grad.sum(0), atol=1e-5)
+    assert torch.allclose(from_acc(dbias[:Cr], ACC_GRAD_BITS).cpu(), lg.grad.sum(0), atol=1e-5)
+    # an out-of-range label: the loss is NaN (TF's GPU kernel), reported through the flag word of the loss buffer
+    bad = labels.clone(); bad[2] = Cr
+    _lib.check(lib.fn_softmax_xent_fwd_bwd(ptr(logits), Cp, ptr(bad), ptr(loss), ptr(dl), Cp, None, N, Cr, 1.0 / N, BF, stream()))
+    assert math.isnan(loss[0].item())
 
 
 def test_pairwise_and_select_triplets(lib):

@@ -8,6 +8,19 @@ from facenet_amd import _lib
 from facenet_amd._lib import ConvDesc
 
 
+# fixed-point accumulators of the C ABI (fn_acc_t, include/facenet_hip.h): value = integer * 2^-bits
+ACC_STAT_BITS, ACC_GRAD_BITS = 20, 40
+
+
+def to_acc(t, bits):
+    """fp tensor -> int64 fixed-point accumulator contents (what a kernel's contributions would have summed to)."""
+    return (t.double() * float(2 ** bits)).round().to(torch.int64)
+
+
+def from_acc(t, bits):
+    return (t.double() / float(2 ** bits)).float()
+
+
 def stream():
     return torch.cuda.current_stream().cuda_stream
 

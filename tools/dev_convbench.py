@@ -10,7 +10,7 @@ def bench(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt=_lib.FN_F16, stats=False, re
     w = (torch.randn(Cout, kh, kw, Cin, device='cuda') * 0.05).to(tdt)
     d = conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt)
     y = torch.zeros(N, d.OH, d.OW, Cout, dtype=tdt, device='cuda')
-    st = torch.zeros(16 * 2 * Cout, device='cuda')
+    st = torch.zeros(16 * 2 * Cout, dtype=torch.int64, device='cuda')
     d.x, d.w, d.y = ptr(x), ptr(w), ptr(y)
     if stats: d.stats, d.stats_sq_off, d.stats_replicas, d.stats_rep_stride = ptr(st), Cout, 16, 2 * Cout
     cur = torch.cuda.current_stream().cuda_stream

@@ -13,7 +13,7 @@ def bench(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt=_lib.FN_BF16, reps=40):
     w = (torch.randn(Cout, kh, kw, Cin, device='cuda') * 0.05).to(tdt)
     d = conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt)
     y = torch.zeros(N, d.OH, d.OW, Cout, dtype=tdt, device='cuda')
-    st = torch.zeros(16, 2 * Cout, device='cuda')      # 16 statistic replicas, as the engine uses for M >= 32K
+    st = torch.zeros(16, 2 * Cout, dtype=torch.int64, device='cuda')      # 16 statistic replicas, as the engine uses for M >= 32K
     d.x, d.w, d.y, d.stats, d.stats_sq_off, d.stats_replicas, d.stats_rep_stride = ptr(x), ptr(w), ptr(y), ptr(st), Cout, 16, 2 * Cout
     cur = torch.cuda.current_stream().cuda_stream
     lib.fn_conv2d_fwd(C.byref(d), cur); torch.cuda.synchronize()
