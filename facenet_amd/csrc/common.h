@@ -119,6 +119,29 @@ template <int FRAC> __device__ __forceinline__ float acc_get(acc_t a) { return (
 // BatchNorm batch statistics -> affine (center only): scale = rstd, shift = beta - mean*rstd.  One definition for the
 // materialising kernel, the normalise-on-load operand path and fn_bn_finalize (the replicas hold fixed-point integers: their sum
 // is exact in any order, so all three produce the same bits).
+// (sum, sum of squares, count) -> mean, biased variance, scale = rstd, shift = beta - mean * rstd.  ONE definition with every
+// rounding spelled out (no fused multiply-add left to the compiler's contraction choices): the materialising kernel, the
+// normalise-on-load prologue and fn_bn_finalize all call it and publish the same bits.
+__device__ __forceinline__ void bn_affine_from_sums(float s1, float s2, int count, float eps, float beta, float& scale, float& shift,
+                                                    float& mean, float& var) {
+#pragma clang fp contract(off)      // (HIP's __fmul_rn & co. are plain operators: only the pragma keeps fused multiply-adds out)
+    const float inv = 1.f / (float)count;
+    mean = s1 * inv;
+    const float ex2 = s2 * inv, m2 = mean * mean;
+    var = fmaxf(ex2 - m2, 0.f);
+    scale = rsqrtf(var + eps);
+    const float ms = mean * scale;
+    shift = beta - ms;
+}
+
+// moving statistic update (Keras: moving * momentum + batch * (1 - momentum)), every rounding spelled out for the same reason
+__device__ __forceinline__ float bn_moving_update(float moving, float batch, float momentum) {
+#pragma clang fp contract(off)
+    const float a = moving * momentum, w = 1.f - momentum;
+    const float b = batch * w;
+    return a + b;
+}
+
 __device__ __forceinline__ void bn_batch_affine(const acc_t* __restrict__ stats, int c, int sq_off, int reps, int rep_stride, int count,
                                                 float eps, float beta, float& scale, float& shift, float& mean, float& var) {
     acc_t s = 0, q = 0;       // replica sums are integer: exact, any order
@@ -126,12 +149,7 @@ __device__ __forceinline__ void bn_batch_affine(const acc_t* __restrict__ stats,
         s += stats[(long)rp * rep_stride + c];
         q += stats[(long)rp * rep_stride + sq_off + c];
     }
-    const float s1 = acc_get<ACC_STAT>(s), s2 = acc_get<ACC_STAT>(q);
-    const float inv = 1.f / (float)count;
-    mean = s1 * inv;
-    var = fmaxf(s2 * inv - mean * mean, 0.f);
-    scale = rsqrtf(var + eps);
-    shift = beta - mean * scale;
+    bn_affine_from_sums(acc_get<ACC_STAT>(s), acc_get<ACC_STAT>(q), count, eps, beta, scale, shift, mean, var);
 }
 
 // Bijective XCD-aware remap: blocks b and b+8 share an XCD (and its 4 MiB L2).  Give each XCD a contiguous run of the

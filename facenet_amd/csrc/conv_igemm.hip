@@ -605,12 +605,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
                 const acc_t* sp = sPart;
                 const float s1 = acc_get<ACC_STAT>(sp[c] + sp[CS + c]);
                 const float s2 = acc_get<ACC_STAT>(sp[2 * CS + c] + sp[3 * CS + c]);
-                const float inv = 1.f / (float)a.nrm_count;
-                const float mean = s1 * inv;
-                const float var = fmaxf(s2 * inv - mean * mean, 0.f);
-                const float sc = rsqrtf(var + a.nrm_eps);
+                float sc, sh, mean, var;
+                bn_affine_from_sums(s1, s2, a.nrm_count, a.nrm_eps, a.nrm_beta[c], sc, sh, mean, var);
                 sNs[c] = sc;
-                sNh[c] = a.nrm_beta[c] - mean * sc;
+                sNh[c] = sh;
             }
             __syncthreads();
         }
@@ -973,7 +971,11 @@ static int choose_conv_ks(int M, int NOUT, int KTOT, int bm, int bn) {
                       // tiles): a second wave per SIMD halves the k chain -- 13.6 -> 10.2 us per launch, step 7.06 -> 7.01 ms; larger grids
                       // (FN_CONV_KS64=400 / 640) and 128-wide tiles measured no gain
         static const int ks64 = getenv("FN_CONV_KS64") ? atoi(getenv("FN_CONV_KS64")) : 256;   // largest grid that splits (0: never)
-        return (force != 1 && bn <= 64 && cdiv(KTOT, 64) >= 8 && (long)cdiv(M, 64) * cdiv(NOUT, bn) <= ks64) ? 2 : 1;
+        // four groups (1024 threads): k chains of >= 12 tiles on at most one workgroup per CU
+        static const int ks64_4 = getenv("FN_CONV_KS64_4") ? atoi(getenv("FN_CONV_KS64_4")) : 0;   // largest grid that splits four ways (0: never)
+        const long grid = (long)cdiv(M, 64) * cdiv(NOUT, bn);
+        if (force != 1 && force != 2 && bn <= 64 && cdiv(KTOT, 64) >= 12 && grid <= ks64_4) return 4;
+        return (force != 1 && bn <= 64 && cdiv(KTOT, 64) >= 8 && grid <= ks64) ? 2 : 1;
     }
     if (bm != 32) return 1;
     const long blocks = (long)cdiv(M, 32) * cdiv(NOUT, bn);
@@ -994,7 +996,7 @@ static int choose_conv_ks(int M, int NOUT, int KTOT, int bm, int bn) {
 #define FN_CONV_VARIANTS(X) X(128, 128, 2, 2, 1, 1) X(128, 64, 2, 2, 2, 1) X(128, 32, 4, 1, 2, 1) X(64, 128, 1, 4, 2, 1) X(64, 64, 2, 2, 2, 1) \
     X(64, 32, 2, 2, 2, 1) X(32, 128, 1, 4, 4, 1) X(32, 64, 1, 4, 4, 1) X(32, 32, 2, 2, 4, 1)                                           \
     X(32, 128, 1, 4, 4, 2) X(32, 64, 1, 4, 4, 2) X(32, 64, 1, 4, 4, 4) X(32, 32, 2, 2, 4, 2) X(32, 32, 2, 2, 4, 4)                       \
-    X(64, 64, 2, 2, 2, 2) X(64, 32, 2, 2, 2, 2)
+    X(64, 64, 2, 2, 2, 2) X(64, 32, 2, 2, 2, 2) X(64, 64, 2, 2, 2, 4) X(64, 32, 2, 2, 2, 4)
 
 // variant code: BM*1000 + BN (+ KS*1000000 when KS > 1)
 static int variant_code(int bm, int bn, int ks) { return bm * 1000 + bn + (ks > 1 ? ks * 1000000 : 0); }

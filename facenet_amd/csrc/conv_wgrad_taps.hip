@@ -148,36 +148,75 @@ __device__ __forceinline__ void conv_wgrad_taps_body(const WgradTapArgs& a, cons
         for (int i = 0; i < MREP; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
-    // One B fragment per tap and k step (2 transposed reads -> MREP MFMAs).  An explicit ring that keeps four fragments in flight
-    // ahead of the MFMAs was measured (counted lgkmcnt, 120 VGPRs -> two waves per SIMD instead of three): 283 vs 261-273 us for
-    // the step's launch -- the three waves a SIMD holds already cover the LDS latency, so the simple form stays.
-    auto compute = [&](int buf) {
+    // ---- pipeline: DEPTH register stages, two LDS buffers, one barrier per tile; branch-free steady state (clamped index) ----
+    // Within an iteration the global loads of tile st+2 and the LDS stores of tile st+1 are spread between the fragment groups of
+    // the MFMA work on tile st (one load / one store per slot) instead of forming a load phase and a store phase.  What the
+    // round-3 ablations of the step's launch showed (FN_WGT_DBG switches, since removed): loads alone 87 us, multiply alone 144 us,
+    // stores 37 us, prologue + epilogue 44 us -- and the whole kernel 290 us, their SUM.  Neither this interleaving (260 vs
+    // 261-273 us), nor a deeper register pipeline (DEPTH 3), nor fragment prefetch, nor staggered workgroup starts changed that;
+    // what does is the number of workgroups a CU holds (513 / 336 / 260 us at 1 / 2 / 3).  MFMA utilisation ~35 %.
+    static_assert(AP + NPL <= 9, "side-task slots");
+    auto iteration = [&](const int buf, const bool do_compute, const int t_next, u32x4 (&ra_n)[AP], u32x4 (&rp_n)[NPL], const u32x4 (&ra_o)[AP],
+                         const u32x4 (&rp_o)[NPL]) {
+        int n, rem, tyi, txi;
+        fast_divmod(t_next, a.tiles_img, a.inv_img, n, rem);
+        fast_divmod(rem, a.tiles_x, a.inv_tx, tyi, txi);
+        const int oy0 = tyi * a.TH, ox0 = txi * a.TW;
+        const int ybase = ((n * a.OH + oy0) * a.OW + ox0) * a.ld_y * 2;
+        const int sy0 = oy0 * a.stride - a.pad_h, sx0 = ox0 * a.stride - a.pad_w;
+        const int xbase = ((n * a.H + sy0) * a.W + sx0) * a.ld_x * 2;     // may be negative; only used where the pixel is inside
         const unsigned char* pa = sA + buf * A_BYTES;
         const unsigned char* pb = sP + buf * a.pbytes;
+        unsigned char* wa = sA + (buf ^ 1) * A_BYTES;
+        unsigned char* wb = sP + (buf ^ 1) * a.pbytes;
+        const bool nine = a.ntaps > 7;
+        // One B fragment per tap and k step (2 transposed reads -> MREP MFMAs), through one register set.  A ring that keeps 1-8
+        // fragments in flight ahead of the MFMAs (counted lgkmcnt) was measured: no gain at equal occupancy (338 us for every
+        // distance at two waves per SIMD) and it costs the third wave per SIMD (260 us) -- the kernel's time follows the waves per
+        // CU (513 / 336 / 260 us at one / two / three workgroups per CU), not the LDS latency of a single wave.
+        constexpr int NFR = 2 * TAPS;
+        vec8 fa[MREP];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            vec8 fa[MREP];
-#pragma unroll
-            for (int i = 0; i < MREP; ++i) {
-                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pa + aoff[ks][0] + i * 32));
-                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pa + aoff[ks][1] + i * 32));
-                fa[i] = __builtin_bit_cast(vec8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
-#pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                // 1x7 / 7x1 layers have seven taps (uniform test; `t` stays a compile-time index: a `break` here sent acc[] to scratch)
-                if (t < 7 || t < a.ntaps) {
-                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb + boff[ks][0] + a.tapoff[t]));
-                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb + boff[ks][1] + a.tapoff[t]));
-                    const vec8 fb = __builtin_bit_cast(vec8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-                    for (int i = 0; i < MREP; ++i) acc[t][i] = LP<T>::mfma(fa[i], fb, acc[t][i]);
+        for (int f = 0; f < NFR; ++f) {
+            if (f % 2 == 0 && f / 2 < AP + NPL) {           // one global load of tile st+2 (slots 0, 2, 4, ...)
+                const int k = f / 2;
+                if (k < AP) {
+                    const int i = k < AP ? k : 0;
+                    const bool ok = a_ok[i] && oy0 + a_ty[i] < a.OH && ox0 + a_tx[i] < a.OW;
+                    ra_n[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, ok ? ybase + a_rel[i] : (int)OOB, 0, 0);
+                } else {
+                    const int j = k >= AP ? k - AP : 0;
+                    const bool ok = p_ok[j] && (unsigned)(sy0 + p_r[j]) < (unsigned)a.H && (unsigned)(sx0 + p_c[j]) < (unsigned)a.W;
+                    rp_n[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? xbase + p_rel[j] : (int)OOB, 0, 0);
                 }
+            }
+            if (f >= TAPS - 1 && (f - (TAPS - 1)) % 2 == 0 && (f - (TAPS - 1)) / 2 < AP + NPL) {   // one LDS store of tile st+1 (slots 8, 10, ...)
+                const int k = (f - (TAPS - 1)) / 2;
+                if (k < AP) {
+                    const int i = k < AP ? k : 0;
+                    *reinterpret_cast<u32x4*>(wa + a_lds[i]) = ra_o[i];
+                } else {
+                    const int j = k >= AP ? k - AP : 0;
+                    if (p_lds[j] >= 0) *reinterpret_cast<u32x4*>(wb + p_lds[j]) = rp_o[j];
+                }
+            }
+            if (do_compute && f % TAPS == 0) {
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) {
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pa + aoff[f / TAPS][0] + i * 32));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pa + aoff[f / TAPS][1] + i * 32));
+                    fa[i] = __builtin_bit_cast(vec8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            }
+            if (do_compute && (f % TAPS < 7 || nine)) {     // 1x7 / 7x1 layers have seven taps (uniform test, compile-time indices)
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb + boff[f / TAPS][0] + a.tapoff[f % TAPS]));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb + boff[f / TAPS][1] + a.tapoff[f % TAPS]));
+                const vec8 fb = __builtin_bit_cast(vec8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) acc[f % TAPS][i] = LP<T>::mfma(fa[i], fb, acc[f % TAPS][i]);
             }
         }
     };
-
-    // ---- pipeline: DEPTH register stages, two LDS buffers, one barrier per tile; branch-free steady state (clamped index) ----
     const int last = tend - 1;
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) load_tile(min(tbeg + d, last), ra[d], rp[d]);
@@ -187,9 +226,7 @@ __device__ __forceinline__ void conv_wgrad_taps_body(const WgradTapArgs& a, cons
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const int st = s0 + d;
-            load_tile(min(tbeg + st + DEPTH, last), ra[d], rp[d]);
-            if (st < nst) compute(st & 1);
-            store_tile((st + 1) & 1, ra[(d + 1) % DEPTH], rp[(d + 1) % DEPTH]);
+            iteration(st & 1, st < nst, min(tbeg + st + DEPTH, last), ra[d], rp[d], ra[(d + 1) % DEPTH], rp[(d + 1) % DEPTH]);
             __syncthreads();
         }
     }

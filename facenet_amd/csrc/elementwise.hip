@@ -171,19 +171,16 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* 
         const int c = c0 + threadIdx.x;
         const float s1 = acc_get<ACC_STAT>(s_part[0][0][threadIdx.x] + s_part[1][0][threadIdx.x] + s_part[2][0][threadIdx.x] + s_part[3][0][threadIdx.x]);
         const float s2v = acc_get<ACC_STAT>(s_part[0][1][threadIdx.x] + s_part[1][1][threadIdx.x] + s_part[2][1][threadIdx.x] + s_part[3][1][threadIdx.x]);
-        const float invM = 1.f / (float)M;
-        const float mean = s1 * invM;
-        const float var = fmaxf(s2v * invM - mean * mean, 0.f);
-        const float rstd = rsqrtf(var + eps);
-        const float shf = beta[c] - mean * rstd;
+        float rstd, shf, mean, var;
+        bn_affine_from_sums(s1, s2v, M, eps, beta[c], rstd, shf, mean, var);
         s_scale[threadIdx.x] = rstd;
         s_shift[threadIdx.x] = shf;
         if (bx_ == 0) {
             save_scale[c] = rstd;
             save_shift[c] = shf;
             if (mm) {
-                mm[c] = mm[c] * momentum + mean * (1.f - momentum);
-                mv[c] = mv[c] * momentum + var * (1.f - momentum);  // biased variance (hazard 3)
+                mm[c] = bn_moving_update(mm[c], mean, momentum);
+                mv[c] = bn_moving_update(mv[c], var, momentum);  // biased variance (hazard 3)
             }
         }
     }
@@ -625,8 +622,8 @@ __global__ __launch_bounds__(64) void head_bn_fwd_kernel(const float* __restrict
 #pragma unroll 8
         for (int n = 0; n < N; ++n) { const float d = y[(long)n * E + c] - mean; q += d * d; }
         var = q / (float)N;
-        mm[c] = mm[c] * momentum + mean * (1.f - momentum);
-        mv[c] = mv[c] * momentum + var * (1.f - momentum);
+        mm[c] = bn_moving_update(mm[c], mean, momentum);
+        mv[c] = bn_moving_update(mv[c], var, momentum);
     } else {
         mean = mm[c];
         var = mv[c];
@@ -800,8 +797,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const acc_t* __restric
     save_scale[c] = sc;
     save_shift[c] = sh;
     if (mm) {
-        mm[c] = mm[c] * momentum + mean * (1.f - momentum);
-        mv[c] = mv[c] * momentum + var * (1.f - momentum);
+        mm[c] = bn_moving_update(mm[c], mean, momentum);
+        mv[c] = bn_moving_update(mv[c], var, momentum);
     }
 }
 
