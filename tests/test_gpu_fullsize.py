@@ -131,7 +131,8 @@ def test_softmax_config4_classifier_10575_classes():
     labels = np.random.default_rng(9).integers(0, Cc, N)
     tr.set_images(torch.from_numpy(structured_images(N, seed=12)), torch.from_numpy(labels))
     st = net.stream()
-    for ops in (tr.pre_ops, tr.plan.fwd, tr.loss_ops):
+    # (the bias gradient is accumulated in fixed point; `grad_finalize`, the last launch of the backward list, moves it into G)
+    for ops in (tr.pre_ops, tr.plan.fwd, tr.loss_ops, [op for op in tr.plan.bwd if op.name == "grad_finalize"]):
         tr.plan.run_ops(ops, st)
     torch.cuda.synchronize()
     params = net.export_keras_params()
