@@ -233,8 +233,9 @@ def group_convs(ops: List[Op], net: Network) -> List[Op]:
 
 
 def adam_beta_powers(t: int, beta1: float, beta2: float) -> Tuple[float, float]:
-    """(beta1^t, beta2^t) as fn_adam_tick derives them from the integer step count: pow in double, rounded to fp32 once."""
-    return float(np.float32(np.float64(beta1) ** t)), float(np.float32(np.float64(beta2) ** t))
+    """(beta1^t, beta2^t) as fn_adam_tick derives them from the integer step count: the betas arrive on the device as fp32, the
+    power is taken in double and rounded to fp32 once."""
+    return float(np.float32(np.float64(np.float32(beta1)) ** t)), float(np.float32(np.float64(np.float32(beta2)) ** t))
 
 
 def _streams_for(net: Network, n_streams: int) -> StreamSet:

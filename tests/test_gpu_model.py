@@ -261,7 +261,8 @@ def test_autotuned_plan_matches_heuristic_plan(monkeypatch, tmp_path):
     assert tiles[0] == {} and len(tiles[2]) > 200 and all(t == 0 or (t // 1000 in (128, 64, 32) and t % 1000 in (128, 64, 32)) for t in tiles[2].values())
     assert all(t != 0 or "conv2d/Conv2d_" in k for k, t in tiles[2].items())            # only stem layers are halo-eligible
     assert tiles[3] == tiles[2] and cache.is_file()                    # second tuned trainer: read back, not re-timed
-    floor = (_rel(results[1][0], results[0][0]), _rel(results[1][1], results[0][1]))
-    for r in results[2:]:
-        d = (_rel(r[0], results[0][0]), _rel(r[1], results[0][1]))
-        assert d[0] <= 3 * floor[0] + 2e-3 and d[1] <= 3 * floor[1] + 2e-2, (d, floor)
+    assert torch.equal(results[1][0], results[0][0]) and torch.equal(results[1][1], results[0][1])      # same plan: same bits
+    assert torch.equal(results[3][0], results[2][0]) and torch.equal(results[3][1], results[2][1])      # cached tiles: the tuned plan again
+    d = (_rel(results[2][0], results[0][0]), _rel(results[2][1], results[0][1]))
+    # other tiles = another summation order; a batch-6 BatchNorm network amplifies the last-bit differences to a few per cent
+    assert d[0] <= 5e-3 and d[1] <= 8e-2, d

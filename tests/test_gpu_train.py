@@ -95,7 +95,9 @@ def test_training_steps_are_reproducible_bit_for_bit(kind):
     """Two trainers from the same weights taking the same three steps end with identical bits: losses, gradients, parameters,
     moving statistics, Adam moments (verdict r02: BN sums and dW went through fp32 atomics and every run differed)."""
     ncls = 23 if kind == "softmax" else None
-    x = torch.from_numpy(structured_images(9, seed=11))
+    xs = structured_images(9, seed=11)
+    xs[2::3] = xs[1::3]                    # negatives = positives: every triplet stays active (loss = alpha) through all three steps
+    x = torch.from_numpy(xs)
     labels = torch.tensor([i % 23 for i in range(9)]) if kind == "softmax" else None
     runs = []
     for _ in range(2):

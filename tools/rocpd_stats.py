@@ -16,7 +16,7 @@ def main():
     if len(sys.argv) > 3:          # optional markdown summary of the top 30
         total = sum(r[2] for r in rows)
         with open(sys.argv[3], "w") as fh:
-            fh.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline   (MI355X, tools/profile_r02.sh)\n")
+            fh.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline   (MI355X, tools/profile_r03.sh)\n")
             fh.write("# the run = warm-up + capture + 20 timed + 10 train-only graph replays + the eager per-launch timing passes (3 bursts of 4, 5 in-step passes);\n")
             fh.write(f"# durations are per kernel launch.  Total kernel time {total / 1e3:.1f} ms.  Names are mangled: IDF16b = __bf16, IDF16_ = _Float16,\n")
             fh.write("# rocprofv3 durations carry ~3 us of per-dispatch floor (adam_tick_kernel: one thread, ~4.7 us here; 1.8 us per launch in a replayed graph).\n")
