@@ -119,7 +119,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
     constexpr int MREP = TM / 16, NREP = TN / 16;
     constexpr int CLD = BN + 4;
     float* sC = reinterpret_cast<float*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = (tid & 255) >> 6;
+    constexpr int GT = 64 * WM * WN;      // threads of the group that owns the accumulators (256, or 512 for the 8-wave tiles)
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid % GT) >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int fr = lane & 15, fq = lane >> 4;
     if (a.stats && active) {  // BatchNorm batch statistics from the fp32 accumulators (rows >= M are exact zeros)
@@ -155,7 +156,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
     }
     __syncthreads();
 
-    constexpr int CG = BN / 8, RP = 256 / CG;
+    constexpr int CG = BN / 8, RP = GT / CG;
     const int cg = tid % CG, rr = tid / CG;
     const int col = n0 + cg * 8;
     float bq1[8], bq2[8];   // fused BN-backward partial sums of this thread's 8 columns
@@ -315,11 +316,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     constexpr bool NORM = MODE == 1, MULTI = MODE == 2;
     static_assert(KS == 1 || MODE == 0, "normalise-on-load / sibling sources are built for KS == 1 only");
     static_assert(!MULTI || PLAIN, "sibling sources are 1x1 layers");
-    constexpr int NT = 256 * KS;
+    constexpr int GT = 64 * WM * WN;      // threads per k group: 256 (4 waves) or 512 (8 waves: the 256-row tiles)
+    constexpr int RPP = GT / 8;           // tile rows one pass of the group's loads covers
+    constexpr int NT = GT * KS;
     constexpr int BK = 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MREP = TM / 16, NREP = TN / 16;
-    constexpr int AP = BM / 32, BP = BN / 32;
+    constexpr int AP = BM / RPP, BP = BN / RPP;
+    static_assert(AP >= 1 && BP >= 1 && (KS == 1 || GT == 256), "tile too small for the thread count / split-K is built for 4-wave groups");
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
     constexpr int STAGE_BYTES = 2 * (A_BYTES + B_BYTES);
     constexpr int CLD = BN + 4;
@@ -328,14 +332,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     typedef typename LP<T>::vec8 vec8;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int grp = KS == 1 ? 0 : (int)(threadIdx.x >> 8);   // split-K group of this thread
+    const int grp = KS == 1 ? 0 : (int)(threadIdx.x / GT);   // split-K group of this thread
     unsigned char* sA = smem + grp * STAGE_BYTES;
     unsigned char* sB = sA + 2 * A_BYTES;
     float* sC = reinterpret_cast<float*>(smem);
     float* sRed = reinterpret_cast<float*>(smem + MAIN_BYTES);         // [WM <= 4][2*BN]: per-row-wave statistic partials
     int4* sT = reinterpret_cast<int4*>(smem + MAIN_BYTES + 8 * BN * 4);  // tap table [ceil(KTOT/64)*8] (general convolutions)
 
-    const int tid = threadIdx.x, gtid = tid & 255, lane = tid & 63, wave = gtid >> 6;
+    const int tid = threadIdx.x, gtid = tid % GT, lane = tid & 63, wave = gtid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     int cls = 0, qy = 0, qx = 0, cls_M = a.M, ktot = a.KTOT, tm, tn, cny = 0, cnx = 0;
     if (!PLAIN && a.s2) {
@@ -395,7 +399,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     unsigned rbyte[AP], wbyte[BP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-        const int m = m0 + r0 + 32 * i;
+        const int m = m0 + r0 + RPP * i;
         ry[i] = 0;
         rx[i] = 0;
         rbyte[i] = OOB;
@@ -411,9 +415,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
                 ry[i] = (py + a.offy - qy) >> 1;     // taps of the class sit at ry - (ky - qy)/2
                 rx[i] = (px + a.offx - qx) >> 1;
                 rbyte[i] = (unsigned)(((n * a.SH + ry[i]) * a.SW + rx[i]) * a.ld_src) * 2u;
-                if (kg == 0 && grp == 0) sRow[r0 + 32 * i] = (n * a.PH + py) * a.PW + px;
+                if (kg == 0 && grp == 0) sRow[r0 + RPP * i] = (n * a.PH + py) * a.PW + px;
             } else if (kg == 0 && grp == 0) {
-                sRow[r0 + 32 * i] = -1;
+                sRow[r0 + RPP * i] = -1;
             }
         } else if (m < a.M) {
             int n, rem, py, px;
@@ -426,7 +430,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     }
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
-        const int co = n0 + r0 + 32 * j;
+        const int co = n0 + r0 + RPP * j;
         wbyte[j] = co < a.NOUT ? (unsigned)co * (unsigned)a.KTOT * 2u : OOB;
     }
     __syncthreads();
@@ -455,13 +459,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
                 const unsigned kb = kk < Ks ? (unsigned)kk * 2u : OOB;
 #pragma unroll
                 for (int i = 0; i < AP; ++i) {
-                    const unsigned m2 = (unsigned)(m0 + r0 + 32 * i) * 2u;
+                    const unsigned m2 = (unsigned)(m0 + r0 + RPP * i) * 2u;
                     const unsigned off = rbyte[i] < 0x40000000u ? m2 * lds + kb : OOB;
                     ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, (int)off, 0, 0);
                 }
 #pragma unroll
                 for (int j = 0; j < BP; ++j) {
-                    const unsigned co2 = (unsigned)(n0 + r0 + 32 * j) * 2u;
+                    const unsigned co2 = (unsigned)(n0 + r0 + RPP * j) * 2u;
                     const unsigned off = wbyte[j] < 0x40000000u ? co2 * (unsigned)Ks + kb : OOB;
                     rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)off, 0, 0);
                 }
@@ -524,7 +528,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         }
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
-            const int r = r0 + 32 * i;
+            const int r = r0 + RPP * i;
             u32x4 v = ra[i];
             if constexpr (NORM) {
                 if (msk & (1u << i)) {
@@ -542,7 +546,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         }
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
-            const int r = r0 + 32 * j;
+            const int r = r0 + RPP * j;
             *reinterpret_cast<u32x4*>(sB + buf * B_BYTES + r * 128 + ((kg ^ (r & 7)) << 4)) = rb[j];
         }
     };
@@ -632,7 +636,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 #pragma unroll
             for (int i = 0; i < MREP; ++i)
 #pragma unroll
-                for (int j = 0; j < NREP; ++j) sX[((grp - 1) * MREP * NREP + i * NREP + j) * 256 + gtid] = acc[i][j];
+                for (int j = 0; j < NREP; ++j) sX[((grp - 1) * MREP * NREP + i * NREP + j) * GT + gtid] = acc[i][j];
         }
         __syncthreads();
         if (grp == 0) {
@@ -641,7 +645,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 #pragma unroll
                 for (int i = 0; i < MREP; ++i)
 #pragma unroll
-                    for (int j = 0; j < NREP; ++j) acc[i][j] += sX[((g - 1) * MREP * NREP + i * NREP + j) * 256 + gtid];
+                    for (int j = 0; j < NREP; ++j) acc[i][j] += sX[((g - 1) * MREP * NREP + i * NREP + j) * GT + gtid];
         }
         __syncthreads();
     }
@@ -652,14 +656,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, int MODE>
-__global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_kernel(const ConvArgs a) {
     conv_igemm_body<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, MODE>(a, blockIdx.x);
 }
 
 // Grouped form: one launch runs several INDEPENDENT convolutions of one tile variant (sibling inception towers, the
 // same dependency level of the launch list): args[g] is layer g, prefix[g] .. prefix[g+1] its workgroups.
 template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, int MODE>
-__global__ __launch_bounds__(256 * KS) void conv_igemm_grouped_kernel(const ConvArgs* __restrict__ args, const int* __restrict__ prefix, int n) {
+__global__ __launch_bounds__(64 * WM * WN * KS) void conv_igemm_grouped_kernel(const ConvArgs* __restrict__ args, const int* __restrict__ prefix, int n) {
     const int bid = blockIdx.x;
     int g = 0;
     while (g + 1 < n && prefix[g + 1] <= bid) ++g;     // n is small (<= 8)
@@ -905,7 +909,7 @@ static int launch_conv_grouped_p(const ConvArgs* dev_args, const int32_t* dev_pr
     auto kern = conv_igemm_grouped_kernel<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, MODE>;
     static LdsOptIn lds_ok;   // one per instantiation
     if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), lds_ok, "conv_igemm_grouped")) return rc;
-    hipLaunchKernelGGL(kern, dim3(total), dim3(256 * KS), smem, st, dev_args, dev_prefix, n);
+    hipLaunchKernelGGL(kern, dim3(total), dim3(64 * WM * WN * KS), smem, st, dev_args, dev_prefix, n);
     return check_launch("conv_igemm_grouped");
 }
 
@@ -921,7 +925,7 @@ static int launch_conv_p(const ConvArgs& a0, hipStream_t st) {
     auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, DEPTH, KS, PLAIN, MODE>;
     static LdsOptIn lds_ok;   // one per instantiation
     if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), lds_ok, "conv_igemm")) return rc;
-    hipLaunchKernelGGL(kern, dim3(a.total_tiles), dim3(256 * KS), smem, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.total_tiles), dim3(64 * WM * WN * KS), smem, st, a);
     return check_launch("conv_igemm");
 }
 
@@ -992,7 +996,11 @@ static int choose_conv_ks(int M, int NOUT, int KTOT, int bm, int bn) {
     return ks;
 }
 
-// tile variants: BM, BN, waves (M x N), register stages, split-K groups
+// tile variants: BM, BN, waves (M x N), register stages, split-K groups.  The body is written for 64 * WM * WN threads per k group;
+// an 8-wave 256x128 variant (512 threads, 48 B of operands per MFMA clock instead of 64-96) was built and measured in round 3
+// (tools/dev_stemtiles.py, 180 images f16): Conv2d_4a 156 us against 129 (128x64), Conv2d_4b 84.8 against 83.7 (128x128),
+// ReductionA 3x3 78 against 68 -- one workgroup per CU runs its load / store / multiply phases strictly one after the other
+// (~4 000 cycles per k tile for 1 024 cycles of MFMA work), so the tuner never picked it and the variant was removed again.
 #define FN_CONV_VARIANTS(X) X(128, 128, 2, 2, 1, 1) X(128, 64, 2, 2, 2, 1) X(128, 32, 4, 1, 2, 1) X(64, 128, 1, 4, 2, 1) X(64, 64, 2, 2, 2, 1) \
     X(64, 32, 2, 2, 2, 1) X(32, 128, 1, 4, 4, 1) X(32, 64, 1, 4, 4, 1) X(32, 32, 2, 2, 4, 1)                                           \
     X(32, 128, 1, 4, 4, 2) X(32, 64, 1, 4, 4, 2) X(32, 64, 1, 4, 4, 4) X(32, 32, 2, 2, 4, 2) X(32, 32, 2, 2, 4, 4)                       \

@@ -186,6 +186,60 @@ def test_conv_wgrad(lib, case, dt):
     assert rel_err(dw, ref) < 2e-5
 
 
+TILE_CASES = [(2, 37, 37, 80, 192, 3, 3, 1, 0, 0),      # 4a: general gather, K tiles straddle taps, 192 = 1.5 x 128 columns
+              (2, 35, 35, 192, 256, 3, 3, 2, 0, 0),     # 4b: stride 2 (parity-class data gradient)
+              (3, 17, 17, 256, 160, 1, 1, 1, 0, 0),     # 1x1 fast path, ragged rows (867) and a ragged column tile
+              (2, 17, 17, 192, 192, 3, 3, 1, 1, 1)]     # 'same' padding
+
+
+@pytest.mark.parametrize("tile", [128128, 128064, 64128, 32032])
+@pytest.mark.parametrize("case", TILE_CASES)
+def test_conv_explicit_tiles(lib, case, tile):
+    """Every tile a caller may pin (fn_conv_desc.tile_fwd / tile_dgrad) gives the convolution, its BatchNorm statistics and the
+    data gradient: forward and data gradient against fp32 references on the same rounded operands."""
+    dt = _lib.FN_BF16
+    N, H, W, Cin, Cout, kh, kw, s, ph, pw = case
+    x = _mk((N, H, W, Cin), dt, seed=71)
+    w = _mk((Cout, kh, kw, Cin), dt, 0.1, seed=72)
+    d = conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt)
+    d.tile_fwd = d.tile_dgrad = tile
+    assert lib.fn_conv2d_variant(C.byref(conv_probe(d)), 0) % 1000000 == tile
+    y = torch.zeros(N, d.OH, d.OW, Cout, dtype=lp_dtype(dt), device="cuda")
+    reps = 4
+    stats_r = torch.zeros(reps, 2 * Cout, dtype=torch.int64, device="cuda")
+    d.x, d.w, d.y, d.stats, d.stats_sq_off, d.stats_replicas, d.stats_rep_stride = ptr(x), ptr(w), ptr(y), ptr(stats_r), Cout, reps, 2 * Cout
+    _lib.check(lib.fn_conv2d_fwd(C.byref(d), stream()))
+    torch.cuda.synchronize()
+    ref = ref_conv(x, w, s, ph, pw)
+    assert rel_err(y, ref) < 6e-3
+    M = N * d.OH * d.OW
+    stats = from_acc(stats_r.sum(0), ACC_STAT_BITS).cpu()
+    assert torch.allclose(stats[:Cout], ref.reshape(M, Cout).sum(0), rtol=2e-3, atol=2e-3 * float(ref.reshape(M, Cout).sum(0).abs().max()))
+    assert torch.allclose(stats[Cout:], (ref.reshape(M, Cout) ** 2).sum(0), rtol=2e-3, atol=1e-3)
+    # data gradient
+    dy = _mk((N, d.OH, d.OW, Cout), dt, seed=73)
+    wt = torch.zeros_like(w).view(-1)
+    table = torch.tensor([[0, Cout, kh * kw * Cin, kh * kw, Cin, -1, -1, 0]], dtype=torch.int32, device="cuda")
+    _lib.check(lib.fn_pack_transpose(ptr(w), ptr(wt), ptr(table), 1, w.numel(), dt, stream()))
+    dx = torch.full((N, H, W, Cin), 3.0, dtype=lp_dtype(dt), device="cuda")
+    g = conv_desc(N, H, W, Cin, Cout, kh, kw, s, ph, pw, dt)
+    g.tile_dgrad = tile
+    g.y, g.w, g.dx = ptr(dy), ptr(wt), ptr(dx)
+    _lib.check(lib.fn_conv2d_dgrad(C.byref(g), stream()))
+    torch.cuda.synchronize()
+    xr = torch.zeros(N, Cin, H, W, requires_grad=True)
+    yr = torch.nn.functional.conv2d(xr, w.float().cpu().permute(0, 3, 1, 2), None, stride=s, padding=(ph, pw))
+    yr.backward(dy.float().cpu().permute(0, 3, 1, 2))
+    assert rel_err(dx, xr.grad.permute(0, 2, 3, 1)) < 6e-3
+
+
+def conv_probe(d):
+    """A copy of the descriptor with dummy pointers where fn_conv2d_variant needs them set."""
+    e = _lib.ConvDesc.from_buffer_copy(d)
+    e.x = e.w = e.y = e.dx = 4096
+    return e
+
+
 TAPS_CASES = [
     # N, H, W, Cin, Cout, kh, kw, stride, ph, pw, ld_x, ld_y, variant
     (2, 19, 19, 32, 64, 3, 3, 1, 0, 0, 32, 64, 5064090),       # 2b-like, 'valid'

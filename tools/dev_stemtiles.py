@@ -39,7 +39,7 @@ def bench(name, N, H, W, Cin, Cout, s, tile, dt=_lib.FN_F16):
     print(f"{name:10s} tile {bm:3d}x{bn:3d}: {best:7.2f} us {fl / best / 1e6:7.1f} TF/s   operand bytes per MFMA clock {(bm + bn) * 128 / (bm * bn / 32):5.1f}", flush=True)
 
 
-for name, shp in (("2b", (180, 77, 77, 32, 64, 1)), ("4a", (180, 37, 37, 80, 192, 1)), ("4b", (180, 35, 35, 192, 256, 2))):
-    for tile in (128128, 128064, 128032, 64128, 64064, 32032):
+for name, shp in (("2b", (180, 77, 77, 32, 64, 1)), ("4a", (180, 37, 37, 80, 192, 1)), ("4b", (180, 35, 35, 192, 256, 2)), ("redA0b", (180, 19, 19, 192, 192, 1))):
+    for tile in (256128, 128128, 128064, 128032, 64128, 64064, 32032):
         if tile % 1000 > 64 and shp[4] <= 64: continue
         bench(name, *shp, tile)
