@@ -24,7 +24,43 @@
 #include "../../include/facenet_hip.h"
 #include "wgrad_taps.h"
 #include <cstdio>
+#include <type_traits>
 #include <cstdlib>
+
+#ifndef FN_IG_DBG
+#define FN_IG_DBG 0     // developer ablations of the k loop (tools/dev_stemtiles.py): 1 no loads, 2 no compute, 4 no LDS stores, 8 no epilogue, 16 no first tile
+#endif
+
+#ifndef FN_IG_DEPTH_MUL
+#define FN_IG_DEPTH_MUL 1
+#endif
+#if FN_IG_DBG & 32      // per-workgroup phase clocks (100 MHz wall clock), summed per kernel class: tools/dev_phases.py
+__device__ unsigned long long fn_ig_phase[256 * 160 * 16];     // 256 replicas: same-address atomics would serialise the whole chip
+extern "C" int fn_debug_phases(unsigned long long* out, int reset) {
+    static unsigned long long host[256 * 160 * 16];
+    if (out) {
+        if (hipMemcpyFromSymbol(host, HIP_SYMBOL(fn_ig_phase), sizeof(host)) != hipSuccess) return -1;
+        for (int i = 0; i < 160 * 16; ++i) {
+            out[i] = 0;
+            for (int r = 0; r < 256; ++r) out[i] += host[r * 160 * 16 + i];
+        }
+    }
+    if (reset) {
+        for (auto& v : host) v = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(fn_ig_phase), host, sizeof(host)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define FN_PHASE_CLOCK(v) const unsigned long long v = wall_clock64()
+#define FN_EP_PARAM , unsigned long long* ep
+#define FN_EP_ARG , ep
+#define FN_EP_STAMP(i) ep[i] = wall_clock64()
+#else
+#define FN_PHASE_CLOCK(v)
+#define FN_EP_PARAM
+#define FN_EP_ARG
+#define FN_EP_STAMP(i)
+#endif
 
 namespace fn {
 
@@ -114,7 +150,7 @@ __device__ __forceinline__ int ktab_entry(int kgroup, int KTOT, int CS, int KW) 
 // `active`: threads 0..255 of the group that owns the accumulators; every thread of the workgroup must call (barriers).
 template <typename T, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], unsigned char* smem, float* sRed,
-                                              const int* sRow, const bool rowtab, const int m0, const int n0, const int tm, const bool active) {
+                                              const int* sRow, const bool rowtab, const int m0, const int n0, const int tm, const bool active FN_EP_PARAM) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MREP = TM / 16, NREP = TN / 16;
     constexpr int CLD = BN + 4;
@@ -155,6 +191,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
                     sC[(wm * TM + i * 16 + fq * 4 + r) * CLD + wn * TN + j * 16 + fr] = acc[i][j][r];
     }
     __syncthreads();
+    FN_EP_STAMP(0);
 
     constexpr int CG = BN / 8, RP = GT / CG;
     const int cg = tid % CG, rr = tid / CG;
@@ -163,30 +200,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bq1[e] = 0.f; bq2[e] = 0.f; }
     if (active && col < a.NOUT) {
-        float bnsc[8], bnsf[8], bnbt[8];
-        if (a.bn_y) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { bnsc[e] = a.bn_scale[col + e]; bnsf[e] = a.bn_shift[col + e]; bnbt[e] = a.bn_beta[col + e]; }
-        }
+        // What a layer's epilogue does beyond bias + ReLU decides its code path (uniform branch).  Each path keeps only its own
+        // operands in registers -- the epilogue is where these kernels peak in VGPRs, and one path carrying every option costs the
+        // main loop a wave per SIMD -- and each requests everything it READS from global memory for a chunk of row passes
+        // before the chunk's first store: with one pass at a time, the wait for a pass's loads also waited for the previous pass's
+        // store (vmcnt counts both on this ISA), one full write round trip per pass, 6-9 us of a 128-row tile's epilogue
+        // (tools/dev_phases.py).  Buffer descriptors make the accesses unconditional: a tile row without a pixel gets the
+        // offset OOB, its loads return zeros and its stores are dropped without touching memory (byte offsets < 2^31).
+        enum { EP_PLAIN = 0, EP_RESID = 1, EP_BNBWD = 2, EP_RESBWD = 3, EP_GENERIC = 4 };
+        const bool full = (col + 8 <= a.NOUT);
+        constexpr int NP = (BM + RP - 1) / RP;
+        constexpr int CHMAX = BM * BN == 128 * 64 ? 2 : 4;    // row passes in flight together; 8 192-element tiles sit one register below an occupancy step
+        constexpr unsigned OOB = 0x80000000u;
+        auto rsrc = [](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, ptr ? 0x7fffffff : 0, 0x00020000); };
+        auto row_pixel = [&](const int row) {
+            if (row >= BM) return -1;
+            if (rowtab) return sRow[row];
+            return m0 + row < a.M ? m0 + row : -1;
+        };
+        auto byte_off = [&](const int m, const int ld) { return (int)(m >= 0 ? (unsigned)(m * ld + col) * 2u : OOB); };
         float bias[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) bias[e] = (a.bias && col + e < a.NOUT) ? a.bias[col + e] : 0.f;
-        float slope[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) slope[e] = (a.prelu && col + e < a.NOUT) ? a.prelu[col + e] : 1.f;
-        const bool full = (col + 8 <= a.NOUT);
-#pragma unroll
-        for (int ps = 0; ps < (BM + RP - 1) / RP; ++ps) {
-            const int row = ps * RP + rr;
-            if (row >= BM) continue;
-            int m = m0 + row;
-            if (rowtab) {
-                m = sRow[row];
-                if (m < 0) continue;
-            } else if (m >= a.M) {
-                continue;
-            }
-            float v[8];
+        auto tile_row = [&](const int row, float (&v)[8]) {      // C tile row + bias
             const f32x4 c0 = *reinterpret_cast<const f32x4*>(&sC[row * CLD + cg * 8]);
             const f32x4 c1 = *reinterpret_cast<const f32x4*>(&sC[row * CLD + cg * 8 + 4]);
 #pragma unroll
@@ -194,79 +230,219 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
                 v[e] = c0[e] + bias[e];
                 v[4 + e] = c1[e] + bias[4 + e];
             }
-            if (a.prelu) {
+        };
+        auto relu8 = [&](float (&v)[8]) {
+            if (a.relu) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : slope[e] * v[e];
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            if (a.resid) {
-                float rv[8];
-                unpack8<T>(*reinterpret_cast<const u32x4*>(a.resid + (long)m * a.ld_res + col), rv);
+        };
+        const int kind = (a.out_f32 || !full || a.prelu || a.accumulate) ? EP_GENERIC
+                         : (a.mask || a.out2)                               ? ((a.mask && a.out2 && !a.bn_y) ? EP_RESBWD : EP_GENERIC)
+                         : a.bn_y                                           ? (a.resid ? EP_GENERIC : EP_BNBWD)
+                         : a.resid                                          ? EP_RESID
+                                                                            : EP_PLAIN;
+#if FN_IG_DBG & 32
+        ep[2] = (unsigned long long)kind;
+#endif
+        if (kind == EP_PLAIN) {            // bias + ReLU: nothing to wait for
+            const __amdgpu_buffer_rsrc_t rs_out = rsrc(a.out);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = rv[e] + a.scale * v[e];
+            for (int ps = 0; ps < NP; ++ps) {
+                const int row = ps * RP + rr;
+                float v[8];
+                tile_row(row < BM ? row : 0, v);
+                relu8(v);
+                __builtin_amdgcn_raw_buffer_store_b128(pack8<T>(v), rs_out, byte_off(row_pixel(row), a.ld_out), 0, 0);
             }
-            const long o = (long)m * a.ld_out + col;
-            if (a.mask) {   // fused residual backward: ReLU mask of the block output, then the scaled copy for the `up` branch
-                float mk[8];
-                unpack8<T>(*reinterpret_cast<const u32x4*>(a.mask + o), mk);
+        } else if (kind == EP_RESID) {     // residual scale-add of the block `up` layers
+            constexpr int CH = NP < CHMAX ? NP : CHMAX;
+            const __amdgpu_buffer_rsrc_t rs_out = rsrc(a.out), rs_res = rsrc(a.resid);
+#pragma unroll 1
+            for (int p0 = 0; p0 < NP; p0 += CH) {
+                int mm[CH];
+                u32x4 q[CH];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+                for (int c = 0; c < CH; ++c) {
+                    mm[c] = row_pixel((p0 + c) * RP + rr);
+                    q[c] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, byte_off(mm[c], a.ld_res), 0, 0);
+                }
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int row = (p0 + c) * RP + rr;
+                    float v[8], rv[8];
+                    tile_row(row < BM ? row : 0, v);
+                    unpack8<T>(q[c], rv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = rv[e] + a.scale * v[e];
+                    relu8(v);
+                    q[c] = pack8<T>(v);
+                }
+#pragma unroll
+                for (int c = 0; c < CH; ++c) __builtin_amdgcn_raw_buffer_store_b128(q[c], rs_out, byte_off(mm[c], a.ld_out), 0, 0);
             }
-            if (a.out2) {
-                float u[8];
+        } else if (kind == EP_BNBWD) {     // data gradient + the BatchNorm-backward sums of the layer that produced its input
+            constexpr int CH = NP < CHMAX ? NP : CHMAX;
+            const __amdgpu_buffer_rsrc_t rs_out = rsrc(a.out), rs_bny = rsrc(a.bn_y);
+            float bnsc[8], bnsf[8], bnbt[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { u[e] = a.scale2 * v[e]; bq1[e] += u[e]; }
-                *reinterpret_cast<u32x4*>(a.out2 + o) = pack8<T>(u);
+            for (int e = 0; e < 8; ++e) { bnsc[e] = a.bn_scale[col + e]; bnsf[e] = a.bn_shift[col + e]; bnbt[e] = a.bn_beta[col + e]; }
+#pragma unroll 1
+            for (int p0 = 0; p0 < NP; p0 += CH) {
+                int mm[CH];
+                u32x4 q[CH];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    mm[c] = row_pixel((p0 + c) * RP + rr);
+                    q[c] = __builtin_amdgcn_raw_buffer_load_b128(rs_bny, byte_off(mm[c], a.ld_bn_y), 0, 0);
+                }
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int row = (p0 + c) * RP + rr;
+                    float v[8], yy[8];
+                    tile_row(row < BM ? row : 0, v);
+                    unpack8<T>(q[c], yy);
+                    if (mm[c] >= 0) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float zf = fmaf(yy[e], bnsc[e], bnsf[e]);
+                            const float gg = (!a.bn_relu || zf > 0.f) ? v[e] : 0.f;
+                            bq1[e] += gg;
+                            bq2[e] += gg * (zf - bnbt[e]);
+                        }
+                    }
+                    relu8(v);
+                    q[c] = pack8<T>(v);
+                }
+#pragma unroll
+                for (int c = 0; c < CH; ++c) __builtin_amdgcn_raw_buffer_store_b128(q[c], rs_out, byte_off(mm[c], a.ld_out), 0, 0);
             }
-            if (a.bn_y) {   // dgrad only (no resid/relu/f32 here): v is the complete gradient unless accumulating
-                float yy[8], tot[8];
-                unpack8<T>(*reinterpret_cast<const u32x4*>(a.bn_y + (long)m * a.ld_bn_y + col), yy);
+        } else if (kind == EP_RESBWD) {    // fused residual backward: [carried gradient +] ReLU mask of the block output, scaled copy for the `up` branch
+            constexpr int CH = NP < 2 ? NP : 2;
+            const __amdgpu_buffer_rsrc_t rs_out = rsrc(a.out), rs_res = rsrc(a.resid), rs_mask = rsrc(a.mask), rs_out2 = rsrc(a.out2);
+#pragma unroll 1
+            for (int p0 = 0; p0 < NP; p0 += CH) {
+                int mm[CH];
+                u32x4 qr[CH], qm[CH];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    tot[e] = v[e];
-                    const float zf = fmaf(yy[e], bnsc[e], bnsf[e]);
-                    const float gg = (!a.bn_relu || zf > 0.f) ? tot[e] : 0.f;
-                    bq1[e] += gg;
-                    bq2[e] += gg * (zf - bnbt[e]);
+                for (int c = 0; c < CH; ++c) {
+                    mm[c] = row_pixel((p0 + c) * RP + rr);
+                    qr[c] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, byte_off(mm[c], a.ld_res), 0, 0);     // zeros without a carried gradient
+                    qm[c] = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, byte_off(mm[c], a.ld_out), 0, 0);
+                }
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int row = (p0 + c) * RP + rr;
+                    float v[8], rv[8], mk[8], u[8];
+                    tile_row(row < BM ? row : 0, v);
+                    if (a.resid) {
+                        unpack8<T>(qr[c], rv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = rv[e] + a.scale * v[e];
+                    }
+                    unpack8<T>(qm[c], mk);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v[e] = mk[e] > 0.f ? v[e] : 0.f;
+                        u[e] = a.scale2 * v[e];
+                        if (mm[c] >= 0) bq1[e] += u[e];
+                    }
+                    relu8(v);
+                    qr[c] = pack8<T>(u);
+                    qm[c] = pack8<T>(v);
+                }
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    __builtin_amdgcn_raw_buffer_store_b128(qr[c], rs_out2, byte_off(mm[c], a.ld_out), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(qm[c], rs_out, byte_off(mm[c], a.ld_out), 0, 0);
                 }
             }
-            if (a.out_f32) {
-                float* op = reinterpret_cast<float*>(a.out) + o;
-                if (full && !a.accumulate) {
-                    if (a.relu) {
+        } else {
+            // everything else, one row pass at a time: fp32 output (logits), ragged column groups, PReLU (MTCNN), accumulating
+            // data gradients, and the combinations the paths above do not name
+            float bnsc[8], bnsf[8], bnbt[8];
+            if (a.bn_y) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                } else {
-                    for (int e = 0; e < 8 && col + e < a.NOUT; ++e) {
-                        float x = v[e] + (a.accumulate ? op[e] : 0.f);
-                        op[e] = a.relu ? fmaxf(x, 0.f) : x;
+                for (int e = 0; e < 8; ++e) { bnsc[e] = a.bn_scale[col + e]; bnsf[e] = a.bn_shift[col + e]; bnbt[e] = a.bn_beta[col + e]; }
+            }
+            float slope[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) slope[e] = (a.prelu && col + e < a.NOUT) ? a.prelu[col + e] : 1.f;
+#pragma unroll 1
+            for (int ps = 0; ps < NP; ++ps) {
+                const int row = ps * RP + rr;
+                const int m = row_pixel(row);
+                if (m < 0) continue;
+                float v[8];
+                tile_row(row, v);
+                if (a.prelu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : slope[e] * v[e];
+                }
+                if (a.resid) {
+                    float rv[8];
+                    unpack8<T>(*reinterpret_cast<const u32x4*>(a.resid + (long)m * a.ld_res + col), rv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = rv[e] + a.scale * v[e];
+                }
+                const long o = (long)m * a.ld_out + col;
+                if (a.mask) {
+                    float mk[8];
+                    unpack8<T>(*reinterpret_cast<const u32x4*>(a.mask + o), mk);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+                }
+                if (a.out2) {
+                    float u[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { u[e] = a.scale2 * v[e]; bq1[e] += u[e]; }
+                    *reinterpret_cast<u32x4*>(a.out2 + o) = pack8<T>(u);
+                }
+                if (a.bn_y) {   // dgrad only (no resid/relu/f32 here): v is the complete gradient unless accumulating
+                    float yy[8];
+                    unpack8<T>(*reinterpret_cast<const u32x4*>(a.bn_y + (long)m * a.ld_bn_y + col), yy);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float zf = fmaf(yy[e], bnsc[e], bnsf[e]);
+                        const float gg = (!a.bn_relu || zf > 0.f) ? v[e] : 0.f;
+                        bq1[e] += gg;
+                        bq2[e] += gg * (zf - bnbt[e]);
                     }
                 }
-            } else {
-                unsigned short* op = reinterpret_cast<unsigned short*>(a.out) + o;
-                if (full) {
-                    if (a.accumulate) {
-                        float pv[8];
-                        unpack8<T>(*reinterpret_cast<const u32x4*>(op), pv);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += pv[e];
+                if (a.out_f32) {
+                    float* op = reinterpret_cast<float*>(a.out) + o;
+                    if (full && !a.accumulate) {
+                        relu8(v);
+                        *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    } else {
+                        for (int e = 0; e < 8 && col + e < a.NOUT; ++e) {
+                            float x = v[e] + (a.accumulate ? op[e] : 0.f);
+                            op[e] = a.relu ? fmaxf(x, 0.f) : x;
+                        }
                     }
-                    if (a.relu) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    *reinterpret_cast<u32x4*>(op) = pack8<T>(v);
                 } else {
-                    for (int e = 0; e < 8 && col + e < a.NOUT; ++e) {
-                        float x = v[e] + (a.accumulate ? LP<T>::to_f32(op[e]) : 0.f);
-                        op[e] = LP<T>::from_f32(a.relu ? fmaxf(x, 0.f) : x);
+                    unsigned short* op = reinterpret_cast<unsigned short*>(a.out) + o;
+                    if (full) {
+                        if (a.accumulate) {
+                            float pv[8];
+                            unpack8<T>(*reinterpret_cast<const u32x4*>(op), pv);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += pv[e];
+                        }
+                        relu8(v);
+                        *reinterpret_cast<u32x4*>(op) = pack8<T>(v);
+                    } else {
+                        for (int e = 0; e < 8 && col + e < a.NOUT; ++e) {
+                            float x = v[e] + (a.accumulate ? LP<T>::to_f32(op[e]) : 0.f);
+                            op[e] = LP<T>::from_f32(a.relu ? fmaxf(x, 0.f) : x);
+                        }
                     }
                 }
             }
         }
     }
+    FN_EP_STAMP(1);
     if (a.bn_y || a.out2) {   // fold the RP row lanes through LDS (the C tile is no longer needed), one atomic per column per block
         __syncthreads();
         float* sP = reinterpret_cast<float*>(smem);   // [RP][2*BN]
@@ -332,6 +508,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     typedef typename LP<T>::vec8 vec8;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    FN_PHASE_CLOCK(ph0);
     const int grp = KS == 1 ? 0 : (int)(threadIdx.x / GT);   // split-K group of this thread
     unsigned char* sA = smem + grp * STAGE_BYTES;
     unsigned char* sB = sA + 2 * A_BYTES;
@@ -583,12 +760,16 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     // Steady state without branches around loads (same reason as above: a conditional load makes the compiler drain the
     // queue).  Tile indices are clamped to the last tile, so the tail re-loads it (L2 hits) and up to DEPTH-1 trailing
     // iterations only move data; nothing reads what they stage.
+#if FN_IG_DBG & 32
+    unsigned long long ph1 = wall_clock64();
+    const unsigned long long phi = ph1;     // index / tap-table prologue done, nothing loaded yet
+#endif
     if (ntiles_k > 0) {
         const int last = ntiles_k - 1;
         const int n_iter = (ntiles_k + KS - 1) / KS;           // same trip count for every group (barriers are block-wide)
         auto tile_of = [&](int it) { return grp + KS * it; };   // it-th k tile of this group
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) load_tile(min(tile_of(d), last), ra[d], rb[d], rmask[d]);
+        for (int d = 0; d < (FN_IG_DBG & 16 ? 0 : DEPTH); ++d) load_tile(min(tile_of(d), last), ra[d], rb[d], rmask[d]);
         if constexpr (NORM) {
             // scale / shift of the source channels from the producer's statistic replicas -- AFTER the first operand loads have
             // been issued, so the two memory round trips overlap; (channel, replica quarter) pairs spread over all threads
@@ -616,16 +797,19 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             }
             __syncthreads();
         }
-        store_tile(0, ra[0], rb[0], rmask[0], min(tile_of(0), last));
+        if (!(FN_IG_DBG & 16)) store_tile(0, ra[0], rb[0], rmask[0], min(tile_of(0), last));
         __syncthreads();
+#if FN_IG_DBG & 32
+        ph1 = wall_clock64();
+#endif
         for (int it0 = 0; it0 < n_iter; it0 += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 const int it = it0 + d;
                 // stage d held this group's tile `it`, already copied to LDS: refill it with tile it+DEPTH
-                load_tile(min(tile_of(it + DEPTH), last), ra[d], rb[d], rmask[d]);
-                if (tile_of(it) < ntiles_k) compute(it & 1);
-                store_tile((it + 1) & 1, ra[(d + 1) % DEPTH], rb[(d + 1) % DEPTH], rmask[(d + 1) % DEPTH], min(tile_of(it + 1), last));
+                if (!(FN_IG_DBG & 1)) load_tile(min(tile_of(it + DEPTH), last), ra[d], rb[d], rmask[d]);
+                if (!(FN_IG_DBG & 2)) if (tile_of(it) < ntiles_k) compute(it & 1);
+                if (!(FN_IG_DBG & 4)) store_tile((it + 1) & 1, ra[(d + 1) % DEPTH], rb[(d + 1) % DEPTH], rmask[(d + 1) % DEPTH], min(tile_of(it + 1), last));
                 __syncthreads();
             }
         }
@@ -652,7 +836,34 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     const bool active = grp == 0;   // group 0 owns the epilogue; the others only keep the barriers company
 
     // ---- epilogue (shared with the halo kernel) -----------------------------------------------------
-    conv_epilogue<T, BM, BN, WM, WN>(a, acc, smem, sRed, sRow, !PLAIN && a.s2, m0, n0, tm, active);
+    if (FN_IG_DBG & 8) return;
+    FN_PHASE_CLOCK(ph2);
+#if FN_IG_DBG & 32
+    unsigned long long ep[4] = {0, 0, 0, 0};
+#endif
+    conv_epilogue<T, BM, BN, WM, WN>(a, acc, smem, sRed, sRow, !PLAIN && a.s2, m0, n0, tm, active FN_EP_ARG);
+#if FN_IG_DBG & 32
+    const unsigned long long ph3a = wall_clock64();
+    __builtin_amdgcn_s_waitcnt(0);          // stores and atomics of the epilogue acknowledged
+    const unsigned long long ph3 = wall_clock64();
+    if (tid == 0) {
+        constexpr int tile = (BM == 128 ? 3 : BM == 64 ? 2 : 1) * 4 + (BN == 128 ? 3 : BN == 64 ? 2 : 1);
+        const int kind = (int)ep[2] + (a.stats ? 5 : 0);      // epilogue path (EP_*), +5: with BatchNorm statistics
+        unsigned long long* p = fn_ig_phase + ((bid & 255) * 160 + (tile & 15) * 10 + kind) * 16;
+        atomicAdd(p + 0, 1ull);
+        atomicAdd(p + 1, phi - ph0);
+        atomicAdd(p + 2, ph1 - phi);
+        atomicAdd(p + 3, ph2 - ph1);
+        atomicAdd(p + 4, ph3 - ph2);
+        atomicAdd(p + 5, (unsigned long long)ntiles_k);
+        atomicAdd(p + 6, (unsigned long long)(PLAIN ? 1 : 0));
+        // epilogue split: C tile in LDS | row passes | folds + atomics | acknowledgement of the stores
+        atomicAdd(p + 7, ep[0] - ph2);
+        atomicAdd(p + 8, ep[1] - ep[0]);
+        atomicAdd(p + 9, ph3a - ep[1]);
+        atomicAdd(p + 10, ph3 - ph3a);
+    }
+#endif
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int DEPTH, int KS, bool PLAIN, int MODE>
@@ -823,7 +1034,10 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a) {
         }
     }
     __syncthreads();        // the C tile overlays the staging buffers
-    conv_epilogue<T, BM, BN, WM, WN>(a, acc, smem, sRed, sRow, true, 0, n0, sp, true);
+#if FN_IG_DBG & 32
+    unsigned long long ep[4];
+#endif
+    conv_epilogue<T, BM, BN, WM, WN>(a, acc, smem, sRed, sRow, true, 0, n0, sp, true FN_EP_ARG);
 }
 
 static size_t halo_smem_bytes(int BN, int KH, int KW) {
@@ -1023,7 +1237,7 @@ template <typename T> static int dispatch_conv(const ConvArgs& a, hipStream_t st
     }
     const int ks = (a.nrm_stats || a.nt_total > 0) ? 1 : choose_conv_ks(a.M, a.NOUT, a.KTOT, bm, bn);
 #define FN_X(BM_, BN_, WM_, WN_, D_, KS_) \
-    if (bm == BM_ && bn == BN_ && ks == KS_) return launch_conv<T, BM_, BN_, WM_, WN_, D_, KS_>(a, st);
+    if (bm == BM_ && bn == BN_ && ks == KS_) return launch_conv<T, BM_, BN_, WM_, WN_, D_ * FN_IG_DEPTH_MUL, KS_>(a, st);
     FN_CONV_VARIANTS(FN_X)
 #undef FN_X
     set_error("conv: no tile variant %dx%d ks=%d", bm, bn, ks);
@@ -1039,11 +1253,11 @@ static int dispatch_conv_grouped(const ConvArgs* dev_args, const int32_t* dev_pr
     if (bm == BM_ && bn == BN_ && ks == KS_) {                                                                                                  \
         if constexpr (KS_ == 1) {                                                                                                               \
             if (norm)                                                                                                                           \
-                return plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, 1, true, 1>(dev_args, dev_prefix, n, total, smem, st)         \
-                             : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, 1, false, 1>(dev_args, dev_prefix, n, total, smem, st);       \
+                return plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_ * FN_IG_DEPTH_MUL, 1, true, 1>(dev_args, dev_prefix, n, total, smem, st)         \
+                             : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_ * FN_IG_DEPTH_MUL, 1, false, 1>(dev_args, dev_prefix, n, total, smem, st);       \
         }                                                                                                                                       \
-        return plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, KS_, true, 0>(dev_args, dev_prefix, n, total, smem, st)              \
-                     : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, KS_, false, 0>(dev_args, dev_prefix, n, total, smem, st);            \
+        return plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_ * FN_IG_DEPTH_MUL, KS_, true, 0>(dev_args, dev_prefix, n, total, smem, st)              \
+                     : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_ * FN_IG_DEPTH_MUL, KS_, false, 0>(dev_args, dev_prefix, n, total, smem, st);            \
     }
     FN_CONV_VARIANTS(FN_X)
 #undef FN_X

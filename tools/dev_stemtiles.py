@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("FN_CONV_HALO", "0")
 from facenet_amd import _lib
 from tests.util import conv_desc, ptr
+if os.environ.get('FN_DEV_LIB'): _lib.LIB_PATH = os.path.abspath(os.environ['FN_DEV_LIB'])     # an experimental build of the library
 lib = _lib.load()
 R = 6
 
@@ -39,7 +40,11 @@ def bench(name, N, H, W, Cin, Cout, s, tile, dt=_lib.FN_F16):
     print(f"{name:10s} tile {bm:3d}x{bn:3d}: {best:7.2f} us {fl / best / 1e6:7.1f} TF/s   operand bytes per MFMA clock {(bm + bn) * 128 / (bm * bn / 32):5.1f}", flush=True)
 
 
+only_layer = sys.argv[1] if len(sys.argv) > 1 else None          # python tools/dev_stemtiles.py [layer [tile]]
+only_tile = int(sys.argv[2]) if len(sys.argv) > 2 else None
 for name, shp in (("2b", (180, 77, 77, 32, 64, 1)), ("4a", (180, 37, 37, 80, 192, 1)), ("4b", (180, 35, 35, 192, 256, 2)), ("redA0b", (180, 19, 19, 192, 192, 1))):
-    for tile in (256128, 128128, 128064, 128032, 64128, 64064, 32032):
+    if only_layer and name != only_layer: continue
+    for tile in (128128, 128064, 128032, 64128, 64064, 32032):
+        if only_tile and tile != only_tile: continue
         if tile % 1000 > 64 and shp[4] <= 64: continue
         bench(name, *shp, tile)
