@@ -318,7 +318,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
                 for (int c = 0; c < CH; ++c) __builtin_amdgcn_raw_buffer_store_b128(q[c], rs_out, byte_off(mm[c], a.ld_out), 0, 0);
             }
         } else if (kind == EP_RESBWD) {    // fused residual backward: [carried gradient +] ReLU mask of the block output, scaled copy for the `up` branch
-            constexpr int CH = NP < 2 ? NP : 2;
+            constexpr int CH = NP < 2 ? NP : 2;      // two operands + two results per pass: four passes in flight cost the 128x128 tile a wave per SIMD
             const __amdgpu_buffer_rsrc_t rs_out = rsrc(a.out), rs_res = rsrc(a.resid), rs_mask = rsrc(a.mask), rs_out2 = rsrc(a.out2);
 #pragma unroll 1
             for (int p0 = 0; p0 < NP; p0 += CH) {
@@ -775,23 +775,51 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             // been issued, so the two memory round trips overlap; (channel, replica quarter) pairs spread over all threads
             acc_t* sPart = reinterpret_cast<acc_t*>(smem + grp * STAGE_BYTES);     // staging LDS is still free: [4][CS] (<= 16 KB)
             const int CS = a.CS;
-            for (int i = tid; i < 2 * CS; i += NT) {
-                const int c = i % CS, q = i / CS;
-                acc_t s1 = 0, s2 = 0;         // fixed-point replicas: integer sums, exact in any order
-                for (int rp = q; rp < a.nrm_replicas; rp += 2) {
-                    s1 += a.nrm_stats[(long)rp * a.nrm_rep_stride + c];
-                    s2 += a.nrm_stats[(long)rp * a.nrm_rep_stride + a.nrm_sq_off + c];
+            // Every load of a trip is in flight at once (2 (channel, half) pairs x 4 replicas x 2 sums per thread; replica
+            // indices are clamped, not branched on): with one replica per loop iteration the prologue was a chain of
+            // nrm_replicas / 2 dependent memory round trips, ~1.2 us each, in front of every normalise-on-load launch.
+            const int R = a.nrm_replicas;
+            for (int i0 = tid; i0 < 2 * CS; i0 += 2 * NT) {
+                acc_t s1[2] = {0, 0}, s2[2] = {0, 0};         // fixed-point replicas: integer sums, exact in any order
+                for (int r0 = 0; r0 < R; r0 += 8) {
+                    acc_t t1[2][4], t2[2][4];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int i = min(i0 + u * NT, 2 * CS - 1);
+                        const int q = i >= CS ? 1 : 0, c = i - q * CS;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const long rp = min(r0 + q + 2 * k, R - 1);
+                            t1[u][k] = a.nrm_stats[rp * a.nrm_rep_stride + c];
+                            t2[u][k] = a.nrm_stats[rp * a.nrm_rep_stride + a.nrm_sq_off + c];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int q = min(i0 + u * NT, 2 * CS - 1) >= CS ? 1 : 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (r0 + q + 2 * k < R) { s1[u] += t1[u][k]; s2[u] += t2[u][k]; }
+                    }
                 }
-                sPart[q * CS + c] = s1;
-                sPart[(2 + q) * CS + c] = s2;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = i0 + u * NT;
+                    if (i < 2 * CS) {
+                        const int q = i >= CS ? 1 : 0, c = i - q * CS;
+                        sPart[q * CS + c] = s1[u];
+                        sPart[(2 + q) * CS + c] = s2[u];
+                    }
+                }
             }
+            const float beta0 = tid < CS ? a.nrm_beta[tid] : 0.f;      // requested before the barrier: off the chain as well
             __syncthreads();
             for (int c = tid; c < CS; c += NT) {      // same arithmetic as bn_batch_affine / bn_relu_fwd_kernel: same bits
                 const acc_t* sp = sPart;
                 const float s1 = acc_get<ACC_STAT>(sp[c] + sp[CS + c]);
                 const float s2 = acc_get<ACC_STAT>(sp[2 * CS + c] + sp[3 * CS + c]);
                 float sc, sh, mean, var;
-                bn_affine_from_sums(s1, s2, a.nrm_count, a.nrm_eps, a.nrm_beta[c], sc, sh, mean, var);
+                bn_affine_from_sums(s1, s2, a.nrm_count, a.nrm_eps, c == tid ? beta0 : a.nrm_beta[c], sc, sh, mean, var);
                 sNs[c] = sc;
                 sNh[c] = sh;
             }
