@@ -148,7 +148,7 @@ __device__ __forceinline__ int ktab_entry(int kgroup, int KTOT, int CS, int KW) 
 // of the producing layer, channel-slice output.  Tile rows map to output pixels either linearly (m0 + row < a.M) or through
 // the row table sRow (-1 = no pixel): the parity classes of a stride-2 data gradient and the 2-D tiles of the halo kernel.
 // `active`: threads 0..255 of the group that owns the accumulators; every thread of the workgroup must call (barriers).
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool MULTI = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], unsigned char* smem, float* sRed,
                                               const int* sRow, const bool rowtab, const int m0, const int n0, const int tm, const bool active FN_EP_PARAM) {
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -207,7 +207,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
         // store (vmcnt counts both on this ISA), one full write round trip per pass, 6-9 us of a 128-row tile's epilogue
         // (tools/dev_phases.py).  Buffer descriptors make the accesses unconditional: a tile row without a pixel gets the
         // offset OOB, its loads return zeros and its stores are dropped without touching memory (byte offsets < 2^31).
-        enum { EP_PLAIN = 0, EP_RESID = 1, EP_BNBWD = 2, EP_RESBWD = 3, EP_GENERIC = 4 };
+        enum { EP_PLAIN = 0, EP_RESID = 1, EP_BNBWD = 2, EP_RESBWD = 3, EP_GENERIC = 4, EP_ACC = 5 };
         const bool full = (col + 8 <= a.NOUT);
         constexpr int NP = (BM + RP - 1) / RP;
         constexpr int CHMAX = BM * BN == 128 * 64 ? 2 : 4;    // row passes in flight together; 8 192-element tiles sit one register below an occupancy step
@@ -237,11 +237,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
         };
-        const int kind = (a.out_f32 || !full || a.prelu || a.accumulate) ? EP_GENERIC
-                         : (a.mask || a.out2)                               ? ((a.mask && a.out2 && !a.bn_y) ? EP_RESBWD : EP_GENERIC)
-                         : a.bn_y                                           ? (a.resid ? EP_GENERIC : EP_BNBWD)
-                         : a.resid                                          ? EP_RESID
-                                                                            : EP_PLAIN;
+        const int kind = (a.out_f32 || !full || a.prelu) ? EP_GENERIC
+                         : a.accumulate                   ? ((a.mask || a.out2 || a.bn_y || a.resid) ? EP_GENERIC : EP_ACC)
+                         : (a.mask || a.out2)             ? ((a.mask && a.out2 && !a.bn_y) ? EP_RESBWD : EP_GENERIC)
+                         : a.bn_y                         ? (a.resid ? EP_GENERIC : EP_BNBWD)
+                         : a.resid                        ? EP_RESID
+                                                          : EP_PLAIN;
 #if FN_IG_DBG & 32
         ep[2] = (unsigned long long)kind;
 #endif
@@ -255,9 +256,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
                 relu8(v);
                 __builtin_amdgcn_raw_buffer_store_b128(pack8<T>(v), rs_out, byte_off(row_pixel(row), a.ld_out), 0, 0);
             }
-        } else if (kind == EP_RESID) {     // residual scale-add of the block `up` layers
+        } else if (kind == EP_RESID || kind == EP_ACC) {     // residual scale-add of the block `up` layers / a data gradient added to an earlier one
             constexpr int CH = NP < CHMAX ? NP : CHMAX;
-            const __amdgpu_buffer_rsrc_t rs_out = rsrc(a.out), rs_res = rsrc(a.resid);
+            const bool acc_mode = kind == EP_ACC;
+            const __amdgpu_buffer_rsrc_t rs_out = rsrc(a.out), rs_res = rsrc(acc_mode ? (const void*)a.out : (const void*)a.resid);
+            const int ld_q = acc_mode ? a.ld_out : a.ld_res;
+            const float vs = acc_mode ? 1.f : a.scale;
 #pragma unroll 1
             for (int p0 = 0; p0 < NP; p0 += CH) {
                 int mm[CH];
@@ -265,7 +269,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
                     mm[c] = row_pixel((p0 + c) * RP + rr);
-                    q[c] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, byte_off(mm[c], a.ld_res), 0, 0);
+                    q[c] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, byte_off(mm[c], ld_q), 0, 0);
                 }
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
@@ -274,7 +278,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
                     tile_row(row < BM ? row : 0, v);
                     unpack8<T>(q[c], rv);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = rv[e] + a.scale * v[e];
+                    for (int e = 0; e < 8; ++e) v[e] = rv[e] + vs * v[e];      // accumulate: vs = 1, the same bits as v + rv
                     relu8(v);
                     q[c] = pack8<T>(v);
                 }
@@ -318,7 +322,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
                 for (int c = 0; c < CH; ++c) __builtin_amdgcn_raw_buffer_store_b128(q[c], rs_out, byte_off(mm[c], a.ld_out), 0, 0);
             }
         } else if (kind == EP_RESBWD) {    // fused residual backward: [carried gradient +] ReLU mask of the block output, scaled copy for the `up` branch
-            constexpr int CH = NP < 2 ? NP : 2;      // two operands + two results per pass: four passes in flight cost the 128x128 tile a wave per SIMD
+            // two operands + two results per pass: four passes in flight cost the single-source 128x128 kernels a wave per SIMD;
+            // the sibling-source kernels (where this path runs) have the registers
+            constexpr int CH = MULTI ? (NP < 4 ? NP : 4) : (NP < 2 ? NP : 2);
             const __amdgpu_buffer_rsrc_t rs_out = rsrc(a.out), rs_res = rsrc(a.resid), rs_mask = rsrc(a.mask), rs_out2 = rsrc(a.out2);
 #pragma unroll 1
             for (int p0 = 0; p0 < NP; p0 += CH) {
@@ -775,20 +781,20 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             // been issued, so the two memory round trips overlap; (channel, replica quarter) pairs spread over all threads
             acc_t* sPart = reinterpret_cast<acc_t*>(smem + grp * STAGE_BYTES);     // staging LDS is still free: [4][CS] (<= 16 KB)
             const int CS = a.CS;
-            // Every load of a trip is in flight at once (2 (channel, half) pairs x 4 replicas x 2 sums per thread; replica
+            // Every load of a trip is in flight at once (2 (channel, half) pairs x 2 replicas x 2 sums per thread; replica
             // indices are clamped, not branched on): with one replica per loop iteration the prologue was a chain of
             // nrm_replicas / 2 dependent memory round trips, ~1.2 us each, in front of every normalise-on-load launch.
             const int R = a.nrm_replicas;
             for (int i0 = tid; i0 < 2 * CS; i0 += 2 * NT) {
                 acc_t s1[2] = {0, 0}, s2[2] = {0, 0};         // fixed-point replicas: integer sums, exact in any order
-                for (int r0 = 0; r0 < R; r0 += 8) {
-                    acc_t t1[2][4], t2[2][4];
+                for (int r0 = 0; r0 < R; r0 += 4) {
+                    acc_t t1[2][2], t2[2][2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int i = min(i0 + u * NT, 2 * CS - 1);
                         const int q = i >= CS ? 1 : 0, c = i - q * CS;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
+                        for (int k = 0; k < 2; ++k) {
                             const long rp = min(r0 + q + 2 * k, R - 1);
                             t1[u][k] = a.nrm_stats[rp * a.nrm_rep_stride + c];
                             t2[u][k] = a.nrm_stats[rp * a.nrm_rep_stride + a.nrm_sq_off + c];
@@ -798,7 +804,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
                     for (int u = 0; u < 2; ++u) {
                         const int q = min(i0 + u * NT, 2 * CS - 1) >= CS ? 1 : 0;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
+                        for (int k = 0; k < 2; ++k)
                             if (r0 + q + 2 * k < R) { s1[u] += t1[u][k]; s2[u] += t2[u][k]; }
                     }
                 }
@@ -869,7 +875,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 #if FN_IG_DBG & 32
     unsigned long long ep[4] = {0, 0, 0, 0};
 #endif
-    conv_epilogue<T, BM, BN, WM, WN>(a, acc, smem, sRed, sRow, !PLAIN && a.s2, m0, n0, tm, active FN_EP_ARG);
+    conv_epilogue<T, BM, BN, WM, WN, MULTI>(a, acc, smem, sRed, sRow, !PLAIN && a.s2, m0, n0, tm, active FN_EP_ARG);
 #if FN_IG_DBG & 32
     const unsigned long long ph3a = wall_clock64();
     __builtin_amdgcn_s_waitcnt(0);          // stores and atomics of the epilogue acknowledged
@@ -890,6 +896,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         atomicAdd(p + 8, ep[1] - ep[0]);
         atomicAdd(p + 9, ph3a - ep[1]);
         atomicAdd(p + 10, ph3 - ph3a);
+        atomicAdd(p + 11, (unsigned long long)((a.out_f32 || a.prelu) ? 1 : 0));      // what sent workgroups down the generic path
+        atomicAdd(p + 12, (unsigned long long)(a.accumulate ? 1 : 0));
+        atomicAdd(p + 13, (unsigned long long)((a.mask || a.out2) ? 1 : 0));
+        atomicAdd(p + 14, (unsigned long long)(a.bn_y ? 1 : 0));
+        atomicAdd(p + 15, (unsigned long long)(a.resid ? 1 : 0));
     }
 #endif
 }
