@@ -28,21 +28,19 @@
 #include <cstdlib>
 
 #ifndef FN_IG_DBG
-#define FN_IG_DBG 0     // developer ablations of the k loop (tools/dev_stemtiles.py): 1 no loads, 2 no compute, 4 no LDS stores, 8 no epilogue, 16 no first tile
+#define FN_IG_DBG 0     // developer builds only (-DFN_IG_DBG=n, tools/dev_stemtiles.py / dev_phases.py): ablations 1 no loads, 2 no multiply, 4 no LDS stores,
+                        // 8 no epilogue, 16 no first tile (results are wrong by construction); 32 per-workgroup phase clocks (results unchanged)
 #endif
 
-#ifndef FN_IG_DEPTH_MUL
-#define FN_IG_DEPTH_MUL 1
-#endif
 #if FN_IG_DBG & 32      // per-workgroup phase clocks (100 MHz wall clock), summed per kernel class: tools/dev_phases.py
-__device__ unsigned long long fn_ig_phase[256 * 160 * 16];     // 256 replicas: same-address atomics would serialise the whole chip
+__device__ unsigned long long fn_ig_phase[256 * 576 * 16];     // 256 replicas: same-address atomics would serialise the whole chip
 extern "C" int fn_debug_phases(unsigned long long* out, int reset) {
-    static unsigned long long host[256 * 160 * 16];
+    static unsigned long long host[256 * 576 * 16];
     if (out) {
         if (hipMemcpyFromSymbol(host, HIP_SYMBOL(fn_ig_phase), sizeof(host)) != hipSuccess) return -1;
-        for (int i = 0; i < 160 * 16; ++i) {
+        for (int i = 0; i < 576 * 16; ++i) {
             out[i] = 0;
-            for (int r = 0; r < 256; ++r) out[i] += host[r * 160 * 16 + i];
+            for (int r = 0; r < 256; ++r) out[i] += host[r * 576 * 16 + i];
         }
     }
     if (reset) {
@@ -515,6 +513,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     FN_PHASE_CLOCK(ph0);
+    {   // The argument block (kernel arguments, or this member's record of a grouped launch) spans eight 64-byte lines of the
+        // scalar cache and its fields are read where they are first used: a chain of cold misses, one per line, spread over
+        // the prologue (and, for normalise-on-load, in front of the statistics round trip).  One dword of every line is requested
+        // here, all misses in flight together.
+        const int* ap = reinterpret_cast<const int*>(&a);
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(ConvArgs) / 64); ++k) {
+            const int t = ap[k * 16];
+            asm volatile("" ::"s"(t));
+        }
+    }
     const int grp = KS == 1 ? 0 : (int)(threadIdx.x / GT);   // split-K group of this thread
     unsigned char* sA = smem + grp * STAGE_BYTES;
     unsigned char* sB = sA + 2 * A_BYTES;
@@ -882,8 +891,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     const unsigned long long ph3 = wall_clock64();
     if (tid == 0) {
         constexpr int tile = (BM == 128 ? 3 : BM == 64 ? 2 : 1) * 4 + (BN == 128 ? 3 : BN == 64 ? 2 : 1);
-        const int kind = (int)ep[2] + (a.stats ? 5 : 0);      // epilogue path (EP_*), +5: with BatchNorm statistics
-        unsigned long long* p = fn_ig_phase + ((bid & 255) * 160 + (tile & 15) * 10 + kind) * 16;
+        const int kind = (int)ep[2] + (a.stats ? 6 : 0);      // epilogue path (EP_*), +6: with BatchNorm statistics
+        unsigned long long* p = fn_ig_phase + ((bid & 255) * 576 + ((tile & 15) * 12 + kind) * 3 + MODE) * 16;
         atomicAdd(p + 0, 1ull);
         atomicAdd(p + 1, phi - ph0);
         atomicAdd(p + 2, ph1 - phi);
@@ -1276,7 +1285,7 @@ template <typename T> static int dispatch_conv(const ConvArgs& a, hipStream_t st
     }
     const int ks = (a.nrm_stats || a.nt_total > 0) ? 1 : choose_conv_ks(a.M, a.NOUT, a.KTOT, bm, bn);
 #define FN_X(BM_, BN_, WM_, WN_, D_, KS_) \
-    if (bm == BM_ && bn == BN_ && ks == KS_) return launch_conv<T, BM_, BN_, WM_, WN_, D_ * FN_IG_DEPTH_MUL, KS_>(a, st);
+    if (bm == BM_ && bn == BN_ && ks == KS_) return launch_conv<T, BM_, BN_, WM_, WN_, D_, KS_>(a, st);
     FN_CONV_VARIANTS(FN_X)
 #undef FN_X
     set_error("conv: no tile variant %dx%d ks=%d", bm, bn, ks);
@@ -1292,11 +1301,11 @@ static int dispatch_conv_grouped(const ConvArgs* dev_args, const int32_t* dev_pr
     if (bm == BM_ && bn == BN_ && ks == KS_) {                                                                                                  \
         if constexpr (KS_ == 1) {                                                                                                               \
             if (norm)                                                                                                                           \
-                return plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_ * FN_IG_DEPTH_MUL, 1, true, 1>(dev_args, dev_prefix, n, total, smem, st)         \
-                             : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_ * FN_IG_DEPTH_MUL, 1, false, 1>(dev_args, dev_prefix, n, total, smem, st);       \
+                return plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, 1, true, 1>(dev_args, dev_prefix, n, total, smem, st)         \
+                             : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, 1, false, 1>(dev_args, dev_prefix, n, total, smem, st);       \
         }                                                                                                                                       \
-        return plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_ * FN_IG_DEPTH_MUL, KS_, true, 0>(dev_args, dev_prefix, n, total, smem, st)              \
-                     : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_ * FN_IG_DEPTH_MUL, KS_, false, 0>(dev_args, dev_prefix, n, total, smem, st);            \
+        return plain ? launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, KS_, true, 0>(dev_args, dev_prefix, n, total, smem, st)              \
+                     : launch_conv_grouped_p<T, BM_, BN_, WM_, WN_, D_, KS_, false, 0>(dev_args, dev_prefix, n, total, smem, st);            \
     }
     FN_CONV_VARIANTS(FN_X)
 #undef FN_X

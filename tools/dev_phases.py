@@ -19,23 +19,24 @@ lib = _lib.load()
 import bench
 
 sys.argv = ["bench.py", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"] + sys.argv[1:]
-buf = (C.c_ulonglong * (160 * 16))()
+buf = (C.c_ulonglong * (576 * 16))()
 try:
     bench.main()
 finally:
     lib.fn_debug_phases.restype = C.c_int
     assert lib.fn_debug_phases(buf, 0) == 0
-    t = np.array(list(buf), dtype=np.float64).reshape(160, 16)
+    t = np.array(list(buf), dtype=np.float64).reshape(576, 16)
     names = {1: 32, 2: 64, 3: 128}
-    kinds = ["plain", "resid", "bn-bwd", "res-bwd", "generic"]
+    kinds = ["plain", "resid", "bn-bwd", "res-bwd", "generic", "accum"]
     print(f"{'tile':>9s} {'epilogue':>12s} {'1x1':>4s} {'WGs':>9s} {'k tiles':>8s} | {'index':>6s} {'first':>6s} {'loop':>7s} {'per kt':>6s} {'epil':>6s} = {'C->LDS':>6s} {'rows':>6s} {'folds':>6s} {'ack':>6s}  us per workgroup | share with f32/prelu accumulate mask/out2 bn_y resid")
-    for i in range(160):
+    for i in range(576):
         n = t[i, 0]
         if n == 0: continue
-        tile, kind = i // 10, i % 10
+        mode = i % 3
+        tile, kind = (i // 3) // 12, (i // 3) % 12
         bm, bn = names.get(tile // 4, 0), names.get(tile % 4, 0)
         u = t[i, 1:5] / n / 100.0
         kt = t[i, 5] / n
         e = t[i, 7:11] / n / 100.0
-        label = kinds[kind % 5] + ("+st" if kind >= 5 else "")
+        label = kinds[kind % 6] + ("+st" if kind >= 6 else "") + ("", "/norm", "/sib")[mode]
         print(f"{bm:4d}x{bn:<4d} {label:>12s} {t[i, 6] / n:4.2f} {int(n):9d} {kt:8.1f} | {u[0]:6.2f} {u[1]:6.2f} {u[2]:7.2f} {u[2] / max(kt, 1):6.3f} {u[3]:6.2f} = {e[0]:6.2f} {e[1]:6.2f} {e[2]:6.2f} {e[3]:6.2f} | " + " ".join(f"{t[i, 11 + k] / n:4.2f}" for k in range(5)))

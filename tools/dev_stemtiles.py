@@ -1,5 +1,8 @@
 """Developer aid: the stem 3x3 layers (180 images, f16) under every implicit-GEMM tile (tile_fwd set per descriptor; FN_CONV_HALO=0 keeps
-the halo kernel out): does the time follow the operand bytes per tile (L2 -> CU bound) or the MFMA work?"""
+the halo kernel out): does the time follow the operand bytes per tile (L2 -> CU bound) or the MFMA work?
+    python tools/dev_stemtiles.py [layer [tile]]           e.g. 4a 128128
+    FN_DEV_LIB=build/dbg/libN.so python tools/dev_stemtiles.py ...    an experimental build (e.g. -DFN_IG_DBG=7: what is left of the
+                                                                       kernel without loads / multiply / LDS stores)"""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("FN_CONV_HALO", "0")
