@@ -45,7 +45,7 @@ def bench(name, N, H, W, Cin, Cout, s, tile, dt=_lib.FN_F16):
 
 only_layer = sys.argv[1] if len(sys.argv) > 1 else None          # python tools/dev_stemtiles.py [layer [tile]]
 only_tile = int(sys.argv[2]) if len(sys.argv) > 2 else None
-for name, shp in (("2b", (180, 77, 77, 32, 64, 1)), ("4a", (180, 37, 37, 80, 192, 1)), ("4b", (180, 35, 35, 192, 256, 2)), ("redA0b", (180, 19, 19, 192, 192, 1))):
+for name, shp in (("b17", (90, 8, 8, 128, 128, 1)), ("2b", (180, 77, 77, 32, 64, 1)), ("4a", (180, 37, 37, 80, 192, 1)), ("4b", (180, 35, 35, 192, 256, 2)), ("redA0b", (180, 19, 19, 192, 192, 1))):
     if only_layer and name != only_layer: continue
     for tile in (128128, 128064, 128032, 64128, 64064, 32032):
         if only_tile and tile != only_tile: continue
