@@ -420,6 +420,10 @@ def main():
     ap.add_argument("--pool", type=int, default=180)
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the dependency scheduler may use (1 = serial)")
     ap.add_argument("--force-segments", action="store_true", help="1 GPU: run the data-parallel segment structure (6 buckets) without the all-reduce")
+    ap.add_argument("--exchange-self", action="store_true",
+                    help="1 GPU: the whole data-parallel step INCLUDING the bucket all-reduces, through a ONE-rank communicator of "
+                         "FACENET_DIST_BACKEND (default nccl = RCCL): the exchange is the identity, the backend calls, the "
+                         "communication stream and its ordering against the captured segments are the real ones")
     ap.add_argument("--dump-ops", default=None, help="write per-launch HIP-event timings (eager) to this JSON file")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / reporting path only: no HIP work (CPU test of --gpus N)")
     args = ap.parse_args()
@@ -453,6 +457,15 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     pg = None
+    if world == 1 and args.exchange_self:
+        import socket
+        import torch.distributed as dist
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        kw = {"device_id": dev} if backend == "nccl" else {}
+        dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
+        pg = dist.group.WORLD
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -538,8 +551,8 @@ def main():
                        "global_batch": B * world, "image": "160x160x3 uint8", "embedding": E, "alpha": 0.2,
                        "optimizer": "Keras Adam eps=0.1 + L2 5e-4", "parallelism": f"dp{world}",
                        "hip_graph": not args.no_graph, "streams": args.streams},
-            "dist_world_size": torch.distributed.get_world_size() if world > 1 else 1,
-            "dist_backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None,
+            "dist_world_size": torch.distributed.get_world_size() if pg is not None else 1,
+            "dist_backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if pg is not None else None,
             "value_train_only": round(B * world * n2 / elapsed_train, 1),
             "ms_per_step_train_only": round(1e3 * elapsed_train / n2, 3),
             "loss_after_warmup": round(float(loss_warm), 5), "final_loss": round(loss, 5),
@@ -565,7 +578,7 @@ def main():
         if not args.no_cpu_baseline:
             out["embedding_l2_err"] = embedding_l2_err(dev)
             out["cpu_baseline"] = cpu_baseline(60, 30, reps=2) if args.cpu_sample else cpu_baseline()
-    if world > 1:
+    if pg is not None:
         # gradient exchange: per-bucket all-reduce time on the communication stream and how much of it backward hides
         # (every rank runs the profiled steps -- they are collective; rank 0 reports its own view)
         xp = trainer.exchange_profile(steps=3)

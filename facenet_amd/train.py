@@ -253,7 +253,11 @@ class Trainer:
         self.group_wgrad = group_wgrad
         # force_segments: a single replica runs the data-parallel step structure (backward cut at the bucket boundaries, one graph
         # per segment, per-segment grouped weight gradients) with the all-reduce left out: what the segmentation alone costs
-        self.segmented = world_size > 1 or force_segments
+        # A process group given together with world_size == 1 still EXCHANGES: the bucket all-reduces run through that one-rank
+        # communicator on the communication stream (identity on the data, the real backend calls and stream ordering) -- how
+        # the RCCL path is exercised on a one-GPU box (bench.py --exchange-self, tests/test_gpu_dp.py).
+        self.exchange = world_size > 1 or process_group is not None
+        self.segmented = self.exchange or force_segments
         if loss not in ("triplet", "softmax"):
             raise ValueError(f"unknown loss {loss!r}")
         if loss == "triplet" and batch % 3:
@@ -339,7 +343,7 @@ class Trainer:
         self._op(self.opt_ops, "pack_transpose", lib.fn_pack_transpose, _ptr(net.W_train), _ptr(net.Wt_train), _ptr(net.table),
                  len(net.layers), net.max_layer_elems, self.dt, r=[region(net.W_train)], w=[region(net.Wt_train)])
         self.buckets = self._make_buckets(n_buckets) if self.segmented else []
-        self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.exchange else None
         self.streams = _streams_for(net, n_streams)
         self.tiles = autotune_convs(self.plan.fwd + self.loss_ops + self.plan.bwd, net)
         self._build_segments()
@@ -431,7 +435,7 @@ class Trainer:
         if not self.segmented:
             launch(0)
             return
-        if self.world == 1:                   # force_segments: the segment structure without the exchange
+        if not self.exchange:                 # force_segments: the segment structure without the exchange
             for i, (sched, _) in enumerate(self.segments):
                 if sched is not None:
                     launch(i)
@@ -462,7 +466,7 @@ class Trainer:
         """Data-parallel runs: per-bucket all-reduce durations (HIP events on the communication stream) and the fraction of
         the exchange that ran while the compute stream was still inside backward (hidden) -- the rest delays the optimiser.
         Runs `steps` ordinary steps (they count as training steps) and reports their mean."""
-        if self.world <= 1:
+        if not self.exchange:
             return {"buckets": [], "allreduce_ms": 0.0, "overlapped_frac": None}
         per_bucket, hidden, total = None, 0.0, 0.0
         for _ in range(steps):

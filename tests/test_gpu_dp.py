@@ -138,3 +138,67 @@ def test_four_replicas_softmax_broadcast_buckets_and_stat_averaging():
     assert not np.array_equal(res[0][3], res[1][3])     # per-replica BatchNorm: local moving statistics differ
     assert np.allclose(res[0][4], sum(r[3] for r in res) / world, rtol=1e-6, atol=1e-7)
     assert float(np.abs(res[0][2] - res[0][1]).max()) > 0
+
+
+def _one_rank_rccl(port, q, use_graph):
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)   # "nccl" IS RCCL on ROCm
+    try:
+        from facenet_amd.engine import Network
+        from facenet_amd.train import Trainer
+        from oracle import facenet_oracle as fo
+        from tests.util_data import structured_images
+        params, _, _ = fo.build_params(128, seed=0)
+        net = Network(embedding_size=128, device="cuda:0", train_dtype=torch.float16)
+        net.load_keras_params(params)
+        tr = Trainer(net, batch=6, loss="triplet", alpha=0.2, lr=0.01, world_size=1, process_group=dist.group.WORLD, n_buckets=4)
+        assert tr.exchange and tr.comm_stream is not None and len(tr.segments) == len(tr.buckets) + 1
+        tr.set_images(torch.from_numpy(structured_images(6, seed=20)))
+        if use_graph:
+            tr.capture()
+            net.load_keras_params(params)
+            tr.reset_optimizer(lr=0.01)
+        for _ in range(2):
+            tr.step()
+        torch.cuda.synchronize()
+        P, G, loss = net.P.cpu().numpy(), tr.G.cpu().numpy(), tr.loss_value()
+        prof = tr.exchange_profile(steps=1)        # (a third step: after the state was read)
+        q.put((P, G, loss, len(prof["buckets"]), dist.get_backend()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_one_rank_rccl_exchange_is_the_identity(use_graph):
+    """The data-parallel step with its bucket all-reduces going through RCCL -- a ONE-rank communicator, all a one-GPU box allows
+    (RCCL refuses two ranks on a device): communicator set-up, every `all_reduce` on the communication stream, its ordering against
+    the eager / captured schedule segments and the profile's events are the real ones; the data must come back unchanged, so two
+    steps end BITWISE where an ordinary single-process trainer ends."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_rccl, args=(_free_port(), q, use_graph))
+    p.start()
+    P, G, loss, n_buckets, backend = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert backend == "nccl" and n_buckets >= 3
+    from facenet_amd.engine import Network
+    from facenet_amd.train import Trainer
+    from oracle import facenet_oracle as fo
+    from tests.util_data import structured_images
+    params, _, _ = fo.build_params(128, seed=0)
+    net = Network(embedding_size=128, device="cuda:0", train_dtype=torch.float16)
+    net.load_keras_params(params)
+    tr = Trainer(net, batch=6, loss="triplet", alpha=0.2, lr=0.01)
+    tr.set_images(torch.from_numpy(structured_images(6, seed=20)))
+    p_start = net.P.clone()
+    for _ in range(2):
+        tr.step()
+    torch.cuda.synchronize()
+    assert float((net.P - p_start).abs().max()) > 0
+    assert np.array_equal(G, tr.G.cpu().numpy())
+    assert np.array_equal(P, net.P.cpu().numpy())
+    assert loss == tr.loss_value()
