@@ -152,6 +152,18 @@ __device__ __forceinline__ void bn_batch_affine(const acc_t* __restrict__ stats,
     bn_affine_from_sums(acc_get<ACC_STAT>(s), acc_get<ACC_STAT>(q), count, eps, beta, scale, shift, mean, var);
 }
 
+// Write-through stores (sc0 sc1) for tensors the NEXT kernel reads.  The eight XCDs' L2s are not coherent with each other: what a
+// kernel leaves dirty in an L2 is written back at the kernel boundary, on the critical path of the next launch.  With write-through
+// the bytes leave for memory while the kernel still runs (measured on the convolution epilogues alone: step 6.785 -> 6.738 ms; the
+// streaming hint `nt` instead: 6.86).  Byte offsets are 32-bit against a descriptor over the tensor's base pointer.
+enum { STORE_WT = 17 };      // aux / cache-policy operand of the buffer-store builtins: sc0 | sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void store_wt(const __amdgpu_buffer_rsrc_t rs, long byte_offset, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_offset, 0, STORE_WT);
+}
+
 // Bijective XCD-aware remap: blocks b and b+8 share an XCD (and its 4 MiB L2).  Give each XCD a contiguous run of the
 // work-item space; every kernel of the step uses the SAME rows->XCD partition (row fraction x/8 .. (x+1)/8 on XCD x), so
 // what one kernel wrote is still in the L2 of the XCD that reads it in the next kernel (per-XCD L2s are not coherent:

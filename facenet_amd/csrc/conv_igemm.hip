@@ -252,7 +252,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
                 float v[8];
                 tile_row(row < BM ? row : 0, v);
                 relu8(v);
-                __builtin_amdgcn_raw_buffer_store_b128(pack8<T>(v), rs_out, byte_off(row_pixel(row), a.ld_out), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(pack8<T>(v), rs_out, byte_off(row_pixel(row), a.ld_out), 0, STORE_WT);
             }
         } else if (kind == EP_RESID || kind == EP_ACC) {     // residual scale-add of the block `up` layers / a data gradient added to an earlier one
             constexpr int CH = NP < CHMAX ? NP : CHMAX;
@@ -281,7 +281,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
                     q[c] = pack8<T>(v);
                 }
 #pragma unroll
-                for (int c = 0; c < CH; ++c) __builtin_amdgcn_raw_buffer_store_b128(q[c], rs_out, byte_off(mm[c], a.ld_out), 0, 0);
+                for (int c = 0; c < CH; ++c) __builtin_amdgcn_raw_buffer_store_b128(q[c], rs_out, byte_off(mm[c], a.ld_out), 0, STORE_WT);
             }
         } else if (kind == EP_BNBWD) {     // data gradient + the BatchNorm-backward sums of the layer that produced its input
             constexpr int CH = NP < CHMAX ? NP : CHMAX;
@@ -317,7 +317,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
                     q[c] = pack8<T>(v);
                 }
 #pragma unroll
-                for (int c = 0; c < CH; ++c) __builtin_amdgcn_raw_buffer_store_b128(q[c], rs_out, byte_off(mm[c], a.ld_out), 0, 0);
+                for (int c = 0; c < CH; ++c) __builtin_amdgcn_raw_buffer_store_b128(q[c], rs_out, byte_off(mm[c], a.ld_out), 0, STORE_WT);
             }
         } else if (kind == EP_RESBWD) {    // fused residual backward: [carried gradient +] ReLU mask of the block output, scaled copy for the `up` branch
             // two operands + two results per pass: four passes in flight cost the single-source 128x128 kernels a wave per SIMD;
@@ -357,8 +357,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[BM
                 }
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
-                    __builtin_amdgcn_raw_buffer_store_b128(qr[c], rs_out2, byte_off(mm[c], a.ld_out), 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(qm[c], rs_out, byte_off(mm[c], a.ld_out), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(qr[c], rs_out2, byte_off(mm[c], a.ld_out), 0, STORE_WT);
+                    __builtin_amdgcn_raw_buffer_store_b128(qm[c], rs_out, byte_off(mm[c], a.ld_out), 0, STORE_WT);
                 }
             }
         } else {

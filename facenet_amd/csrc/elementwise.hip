@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* 
     }
     __syncthreads();
     if (tx >= ncg) return;
+    const __amdgpu_buffer_rsrc_t rs_z = wt_rsrc(z);
     float sc[8], sf[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = s_scale[tx * 8 + e]; sf[e] = s_shift[tx * 8 + e]; }
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const unsigned short* 
                 const float zf = fmaf(v[e], sc[e], sf[e]);
                 v[e] = relu ? fmaxf(zf, 0.f) : zf;
             }
-            *reinterpret_cast<u32x4*>(z + (long)rr * ld_z + c) = pack8<T>(v);
+            store_wt(rs_z, ((long)rr * ld_z + c) * 2, pack8<T>(v));
         }
     }
 }
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(unsigned short* 
     }
     __syncthreads();
     if (tx >= ncg) return;
+    const __amdgpu_buffer_rsrc_t rs_dz = wt_rsrc(dz);
     float k1[8], k2[8], sc[8], sf[8], bt[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(unsigned short* 
                 const float gg = (!relu || zf > 0.f) ? g[e] : 0.f;
                 g[e] = sc[e] * (gg - k1[e] - (zf - bt[e]) * k2[e]);
             }
-            *reinterpret_cast<u32x4*>(dz + (long)rr * ld_d + c) = pack8<T>(g);
+            store_wt(rs_dz, ((long)rr * ld_d + c) * 2, pack8<T>(g));
         }
     }
 }
