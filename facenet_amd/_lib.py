@@ -55,6 +55,7 @@ _SIGNATURES = {
     "fn_conv2d_variant": [C.POINTER(ConvDesc), _i],
     "fn_block35_infer": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _i, _i, _p],
     "fn_block17_infer": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _i, _i, _p],
+    "fn_block17_infer_warm": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _i, _p, C.c_int64, _i, _p],
     "fn_conv2d_arg_bytes": [],
     "fn_conv2d_group_build": [C.POINTER(ConvDesc), _i, _i, _i, _p, _p, _p],
     "fn_conv2d_grouped": [_p, _p, _i, _i, _i, _i, _i, _i, _p],

@@ -42,7 +42,33 @@ struct Block17Args {
     float scale;
     int relu;
     int N;
+    const unsigned char* warm;     // optional: bytes the NEXT launch streams (its weight packs), touched by extra workgroups
+    long warm_bytes;
 };
+
+// Workgroups beyond the images of a fused-block launch (blockIdx.x >= N; the launch adds WARM_WGS of them when asked to) read a
+// byte range into the L2 of their XCD and leave.  One image per workgroup uses 180 of the 256 CUs, so they run on idle CUs next to
+// the block's own work; workgroup ids go round the eight XCDs, so the j-th extra workgroup sits on XCD (N + j) % 8 and is that
+// XCD's (j / 8)-th: it takes eighth j / 8 of the range, every XCD ends up with all of it.  What it buys: the next Block17 streams
+// 1.38 MB of weights per workgroup through a dependent chain of k steps; from memory that chain costs 50 us per launch, from a warm
+// L2 39 us (measured by pointing all ten blocks at one block's weights).
+enum { WARM_WGS = 64 };
+__device__ __forceinline__ void warm_range(const unsigned char* p, long bytes, int j, int nthreads) {
+    const long per = ((bytes + 8 * 16 - 1) / (8 * 16)) * 16;     // eighths in whole 16-byte chunks
+    const long lo = (long)(j >> 3) * per, hi = lo + per < bytes ? lo + per : bytes;
+    unsigned acc = 0u;
+    for (long o = lo + (long)threadIdx.x * 16; o + 16 <= hi; o += (long)nthreads * 16 * 4) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long oo = o + (long)u * nthreads * 16;
+            v[u] = oo + 16 <= hi ? *reinterpret_cast<const u32x4*>(p + oo) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc ^= v[u][0];
+    }
+    asm volatile("" ::"v"(acc));      // the loads are the effect: keep them
+}
 
 __device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 2) & 1) << 1)) << 4); }
 
@@ -120,6 +146,10 @@ __global__ __launch_bounds__(512) void block17_infer_kernel(const Block17Args a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wq = wave & 3, wh = wave >> 2;
     const int fr = lane & 15, fq = lane >> 4;
     const int img = blockIdx.x;
+    if (img >= a.N) {         // warm-ahead workgroup (uniform per workgroup: no barrier is skipped by part of one)
+        warm_range(a.warm, a.warm_bytes, img - a.N, 512);
+        return;
+    }
     const unsigned short* xin = a.x + (long)img * NPIX * C;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xin), 0, NPIX * C * 2, 0x00020000);
 
@@ -684,12 +714,23 @@ using namespace fn;
 extern "C" int fn_block17_infer(const void* x, void* y, int N, const void* w_t0, const void* w_t1a, const void* w_t1b, const void* w_t1c,
                                 const void* w_up, const float* b_t0, const float* b_t1a, const float* b_t1b, const float* b_t1c, const float* b_up,
                                 float scale, int relu, int dtype, void* stream) {
+    return fn_block17_infer_warm(x, y, N, w_t0, w_t1a, w_t1b, w_t1c, w_up, b_t0, b_t1a, b_t1b, b_t1c, b_up, scale, relu, nullptr, 0, dtype, stream);
+}
+
+// The same launch plus WARM_WGS workgroups that read [warm, warm + warm_bytes) -- what the NEXT launch will stream, normally the
+// weight packs of the next block -- into every XCD's L2 (see warm_range).  warm == nullptr: exactly fn_block17_infer.
+extern "C" int fn_block17_infer_warm(const void* x, void* y, int N, const void* w_t0, const void* w_t1a, const void* w_t1b, const void* w_t1c,
+                                     const void* w_up, const float* b_t0, const float* b_t1a, const float* b_t1b, const float* b_t1c,
+                                     const float* b_up, float scale, int relu, const void* warm, int64_t warm_bytes, int dtype, void* stream) {
     FN_REQUIRE(dtype == FN_BF16 || dtype == FN_F16, "dtype %d unsupported", dtype);
+    FN_REQUIRE((warm == nullptr) == (warm_bytes == 0) && warm_bytes >= 0 && warm_bytes < (1L << 31) && ((uintptr_t)warm & 15) == 0,
+               "block17_infer: warm range must be 16-byte aligned, below 2 GiB, and given with its size");
     FN_REQUIRE(x && y && x != y && N > 0 && w_t0 && w_t1a && w_t1b && w_t1c && w_up && b_t0 && b_t1a && b_t1b && b_t1c && b_up,
                "block17_infer: bad arguments");
     Block17Args a{(const unsigned short*)x, (unsigned short*)y, (const unsigned short*)w_t0, (const unsigned short*)w_t1a,
                   (const unsigned short*)w_t1b, (const unsigned short*)w_t1c, (const unsigned short*)w_up, b_t0, b_t1a, b_t1b, b_t1c, b_up,
-                  scale, relu, N};
+                  scale, relu, N, (const unsigned char*)warm, (long)warm_bytes};
+    const int grid = N + (warm ? WARM_WGS : 0);
     constexpr size_t smem = 8 * 64 * 64 + 2 * 4 * 112 * 64 + 3 * 16 * 1024;      // staging: 2 x 20 KB (register ring) or 3 x 16 KB (LDS-DMA)
     static const int use_dma = getenv("FN_B17_DMA") ? atoi(getenv("FN_B17_DMA")) : 1;   // measured: stages 2+3 12.4 -> 9.6 us per block (tools/dev_block17.py)
     static LdsOptIn ok[4];
@@ -698,11 +739,11 @@ extern "C" int fn_block17_infer(const void* x, void* y, int N, const void* w_t0,
     const int which = (use_dma ? 2 : 0) + (dtype == FN_BF16 ? 0 : 1);
     if (int rc = allow_big_lds(kerns[which], ok[which], "block17_infer")) return rc;
     if (use_dma) {
-        if (dtype == FN_BF16) hipLaunchKernelGGL((block17_infer_kernel<__bf16, true>), dim3(N), dim3(512), smem, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((block17_infer_kernel<_Float16, true>), dim3(N), dim3(512), smem, (hipStream_t)stream, a);
+        if (dtype == FN_BF16) hipLaunchKernelGGL((block17_infer_kernel<__bf16, true>), dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((block17_infer_kernel<_Float16, true>), dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
     } else {
-        if (dtype == FN_BF16) hipLaunchKernelGGL((block17_infer_kernel<__bf16, false>), dim3(N), dim3(512), smem, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((block17_infer_kernel<_Float16, false>), dim3(N), dim3(512), smem, (hipStream_t)stream, a);
+        if (dtype == FN_BF16) hipLaunchKernelGGL((block17_infer_kernel<__bf16, false>), dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((block17_infer_kernel<_Float16, false>), dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
     }
     return check_launch("block17_infer");
 }

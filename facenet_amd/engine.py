@@ -896,8 +896,22 @@ class Lowering:
         bs = [_ptr(net.fold_bias, L.bn_off) for L in Ls[:4]] + [_ptr(net.P, Ls[4].bias_off)]
         reads = [self._ra(r.x)] + [region(net.W_infer, L.w_off, L.w_off + L.numel) for L in Ls] + \
                 [region(net.fold_bias, L.bn_off, L.bn_off + L.cout) for L in Ls[:4]] + [region(net.P, Ls[4].bias_off, Ls[4].bias_off + Ls[4].cout)]
-        self._emit(self.fwd, "block17_fused:" + pre, net.lib.fn_block17_infer, _ptr(r.x.buf.act), _ptr(r.y.buf.act), self.N, *ws, *bs,
-                   r.extra["scale"], 1 if r.extra["relu"] else 0, self.dt, r=reads, w=[self._ra(r.y)])
+        # warm-ahead: the launch's spare workgroups (180 images on 256 CUs) read the NEXT block's weight packs into every XCD's L2
+        # (fn_block17_infer_warm): from memory the next block's weight stream costs 50 us per launch, from a warm L2 ~40
+        warm, warm_bytes = None, 0
+        head, _, idx = pre.rpartition("/")
+        if idx.isdigit() and f"{head}/{int(idx) + 1}/up" in net.layers and int(os.environ.get("FACENET_WARM_AHEAD", "1")):
+            nxt = [net.layers[f"{head}/{int(idx) + 1}/{n}"] for n in ("tower_conv0/Conv2d_1x1", "tower_conv1/Conv2d_0a_1x1",
+                                                                      "tower_conv1/Conv2d_0b_1x7", "tower_conv1/Conv2d_0c_7x1", "up")]
+            lo, hi = min(L.w_off for L in nxt), max(L.w_off + L.numel for L in nxt)
+            if hi - lo <= 2 * sum(L.numel for L in nxt):          # the five packs sit (nearly) back to back in the inference buffer
+                esz = net.W_infer.element_size()
+                lo -= lo % (16 // esz)
+                warm, warm_bytes = _ptr(net.W_infer, lo), ((hi - lo) * esz + 15) // 16 * 16
+                warm_bytes = min(warm_bytes, (net.W_infer.numel() - lo) * esz // 16 * 16)
+                reads = reads + [region(net.W_infer, lo, hi)]
+        self._emit(self.fwd, "block17_fused:" + pre, net.lib.fn_block17_infer_warm, _ptr(r.x.buf.act), _ptr(r.y.buf.act), self.N, *ws, *bs,
+                   r.extra["scale"], 1 if r.extra["relu"] else 0, warm, warm_bytes, self.dt, r=reads, w=[self._ra(r.y)])
 
     def _fwd_bn(self, r: Rec):
         if not self.training:

@@ -132,6 +132,12 @@ typedef struct fn_conv_desc {
 int fn_block17_infer(const void* x, void* y, int N, const void* w_t0, const void* w_t1a, const void* w_t1b, const void* w_t1c, const void* w_up,
                      const float* b_t0, const float* b_t1a, const float* b_t1b, const float* b_t1c, const float* b_up, float scale, int relu,
                      int dtype, void* stream);
+/* fn_block17_infer plus 64 extra workgroups (on CUs the one-image-per-workgroup launch leaves idle) that read
+ * [warm, warm + warm_bytes) into every XCD's L2: the bytes the NEXT launch streams, normally the next block's weight packs
+ * (16-byte aligned, < 2 GiB).  Results are those of fn_block17_infer; warm == NULL (with warm_bytes 0) is fn_block17_infer. */
+int fn_block17_infer_warm(const void* x, void* y, int N, const void* w_t0, const void* w_t1a, const void* w_t1b, const void* w_t1c,
+                          const void* w_up, const float* b_t0, const float* b_t1a, const float* b_t1b, const float* b_t1c, const float* b_up,
+                          float scale, int relu, const void* warm, int64_t warm_bytes, int dtype, void* stream);
 /* One Inception-ResNet-A block ("Block35", inception_resnet_v1.py:83-150) of the BN-folded inference network in ONE launch (seven
  * convolution launches otherwise): x, y [N,17,17,256]; w_1x1 / b_1x1: the three tower-entry 1x1 layers (tower_conv0/Conv2d_1x1,
  * tower_conv1/Conv2d_0a_1x1, tower_conv2/Conv2d_0a_1x1); w_3x3 / b_3x3: tower_conv1/Conv2d_0b_3x3, tower_conv2/Conv2d_0b_3x3,
