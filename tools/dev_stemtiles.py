@@ -39,7 +39,7 @@ def bench(name, N, H, W, Cin, Cout, s, tile, dt=_lib.FN_F16):
         a.record(); g.replay(); e.record(); torch.cuda.synchronize()
         best = min(best, a.elapsed_time(e) * 1e3 / (3 * R))
     fl = 2.0 * N * ds[0].OH * ds[0].OW * Cout * 9 * Cin
-    bm, bn = tile // 1000, tile % 1000
+    bm, bn = (tile // 1000, tile % 1000) if tile < 9000000 else (128, 64)      # 9000000: the halo-tile kernel (8 or 16 x 16 pixels)
     print(f"{name:10s} tile {bm:3d}x{bn:3d}: {best:7.2f} us {fl / best / 1e6:7.1f} TF/s   operand bytes per MFMA clock {(bm + bn) * 128 / (bm * bn / 32):5.1f}", flush=True)
 
 
@@ -47,7 +47,7 @@ only_layer = sys.argv[1] if len(sys.argv) > 1 else None          # python tools/
 only_tile = int(sys.argv[2]) if len(sys.argv) > 2 else None
 for name, shp in (("b17", (90, 8, 8, 128, 128, 1)), ("2b", (180, 77, 77, 32, 64, 1)), ("4a", (180, 37, 37, 80, 192, 1)), ("4b", (180, 35, 35, 192, 256, 2)), ("redA0b", (180, 19, 19, 192, 192, 1))):
     if only_layer and name != only_layer: continue
-    for tile in (128128, 128064, 128032, 64128, 64064, 32032):
+    for tile in (128128, 128064, 128032, 64128, 64064, 32032, 9000000):
         if only_tile and tile != only_tile: continue
         if tile % 1000 > 64 and shp[4] <= 64: continue
         bench(name, *shp, tile)
