@@ -91,7 +91,6 @@ struct ConvArgs {
     // of matching parity, so each class is its own GEMM (M = its pixels, K = its taps) inside one launch.
     int s2;                 // 1 = class mode
     int cp1, cp2, cp3;      // first tile of classes 1..3 (class 0 starts at 0)
-    int ny0, ny1, ny2, ny3, nx0, nx1, nx2, nx3;   // pixels per image row / column of every class (scalars: no indexing)
     int total_tiles;
     int src_bytes, w_bytes;   // extents for the buffer resource descriptors (< 2^30)
     int tile;                 // 0 = heuristic, BM*1000+BN = caller's choice (fn_conv_desc.tile_fwd / tile_dgrad)
@@ -538,14 +537,19 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         // static indices only: in the grouped kernel `a` lives in registers and a dynamic index would send it to scratch
         const int t = xcd_remap(bid, a.total_tiles);
         int cp = 0;
-        cny = a.ny0; cnx = a.nx0;
-        if (t >= a.cp1) { cls = 1; cp = a.cp1; cny = a.ny1; cnx = a.nx1; }
-        if (t >= a.cp2) { cls = 2; cp = a.cp2; cny = a.ny2; cnx = a.nx2; }
-        if (t >= a.cp3) { cls = 3; cp = a.cp3; cny = a.ny3; cnx = a.nx3; }
+        if (t >= a.cp1) { cls = 1; cp = a.cp1; }
+        if (t >= a.cp2) { cls = 2; cp = a.cp2; }
+        if (t >= a.cp3) { cls = 3; cp = a.cp3; }
         const int lt = t - cp;
         rcp_divmod(lt, a.tiles_n, tm, tn);
         qy = cls >> 1;
         qx = cls & 1;
+        // pixels per image column / row of the class, recomputed (plan_tiles has the same formula).  As eight argument fields selected
+        // by the class they became an indexed load from a STACK copy of the arguments: 40 bytes of scratch in every general
+        // (non-1x1) variant of this kernel, stride-2 data gradient or not, and a scratch set-up at every wave launch.
+        const int y0 = (qy - a.offy) & 1, x0 = (qx - a.offx) & 1;       // first pixel of the class
+        cny = a.PH > y0 ? (a.PH - y0 + 1) >> 1 : 0;
+        cnx = a.PW > x0 ? (a.PW - x0 + 1) >> 1 : 0;
         cls_M = (a.M / (a.PH * a.PW)) * cny * cnx;
         ktot = ((a.KH - qy + 1) >> 1) * ((a.KW - qx + 1) >> 1) * a.CS;
     } else {
@@ -1153,8 +1157,6 @@ static void plan_tiles(ConvArgs& a, int BM, int BN) {
         t += cdiv(nimg * ny[c] * nx[c], BM) * a.tiles_n;
     }
     a.cp1 = pre[1]; a.cp2 = pre[2]; a.cp3 = pre[3];
-    a.ny0 = ny[0]; a.ny1 = ny[1]; a.ny2 = ny[2]; a.ny3 = ny[3];
-    a.nx0 = nx[0]; a.nx1 = nx[1]; a.nx2 = nx[2]; a.nx3 = nx[3];
     a.tiles_m = 0;
     a.total_tiles = t;
 }
