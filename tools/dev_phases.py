@@ -14,7 +14,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from facenet_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "build", "dbg", "lib32.so")
+_lib.LIB_PATH = os.environ.get("FN_DEV_LIB") or os.path.join(ROOT, "build", "dbg", "lib32.so")
 lib = _lib.load()
 import bench
 
