@@ -164,3 +164,41 @@ def test_batchnorm_statistics_with_mean_far_from_zero(dt, lib):
     assert e_z[r50].max() < 5e-3 and e_z[r0].max() < 1e-4
     assert r_rstd[r200].max() < 1e-2 and e_z[r200].max() < 5e-2
     assert e_mv < 1e-3
+
+
+def test_block17_warm_ahead_entry_point(lib):
+    """fn_block17_infer_warm: the warm-ahead workgroups (block index >= N: they only read [warm, warm + warm_bytes) into L2) change no bit
+    of the output, whatever the range -- including one that is no multiple of the 8 x 16-byte eighths -- and a range without a size, a
+    misaligned range or a negative size is FN_EINVAL with nothing launched."""
+    from facenet_amd import _lib
+    from tests.util import ptr, stream
+    torch.manual_seed(3)
+    N, dt = 5, torch.float16
+    x = (torch.randn(N, 8, 8, 896, device="cuda") * 0.5).to(dt)
+    ws = [(torch.randn(*s, device="cuda") * 0.03).to(dt) for s in ((128, 896), (128, 896), (128, 7, 128), (128, 7, 128), (896, 256))]
+    bs = [torch.randn(n, device="cuda") * 0.1 for n in (128, 128, 128, 128, 896)]
+    junk = torch.randn(70001, device="cuda").to(dt)                     # 140 002 bytes: ragged against every chunking
+
+    def run(warm, nbytes):
+        y = torch.zeros_like(x)
+        _lib.check(lib.fn_block17_infer_warm(ptr(x), ptr(y), N, *[ptr(w) for w in ws], *[ptr(b) for b in bs], 0.1, 1, warm, nbytes,
+                                              _lib.FN_F16, stream()))
+        torch.cuda.synchronize()
+        return y
+
+    ref = torch.zeros_like(x)
+    _lib.check(lib.fn_block17_infer(ptr(x), ptr(ref), N, *[ptr(w) for w in ws], *[ptr(b) for b in bs], 0.1, 1, _lib.FN_F16, stream()))
+    torch.cuda.synchronize()
+    assert float(ref.float().abs().max()) > 0
+    assert torch.equal(run(None, 0), ref)
+    assert torch.equal(run(ptr(junk), 140000 // 16 * 16), ref)
+    assert torch.equal(run(ptr(ws[4]), ws[4].numel() * 2), ref)
+    assert torch.equal(run(ptr(junk), 16), ref)
+    for warm, nbytes in ((ptr(junk), 0), (None, 64), (ptr(junk) + 2, 64), (ptr(junk), -16)):
+        y = torch.zeros_like(x)
+        with pytest.raises(ValueError):
+            _lib.check(lib.fn_block17_infer_warm(ptr(x), ptr(y), N, *[ptr(w) for w in ws], *[ptr(b) for b in bs], 0.1, 1, warm, nbytes,
+                                                  _lib.FN_F16, stream()))
+        torch.cuda.synchronize()
+        assert float(y.float().abs().max()) == 0.0                      # nothing was launched
+    assert b"warm" in lib.fn_last_error()
