@@ -575,6 +575,26 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, a.w_bytes, 0x00020000);
     // NORM with nrm_z: the workgroups of the first column tile also write the normalised operand (the activated tensor)
     const bool side_write = NORM && a.nrm_z != nullptr && tn == 0;
+    // The weights of this group's first k tile are requested NOW, before the tap table and the row arithmetic: they only need the
+    // column tile, and they are the colder operand (the activations were just written by the previous kernel, the weight pack was
+    // last touched a step ago).  Column c of the pack at k index k sits at byte (c * KTOT + k) * 2 for the linear tap order; the
+    // parity classes of a stride-2 data gradient and the sibling sources order their taps differently and load with the tile.
+    const int kg = gtid & 7, r0 = gtid >> 3;
+    u32x4 ra[DEPTH][AP], rb[DEPTH][BP];   // tile t lives in register stage t % DEPTH
+    unsigned rmask[DEPTH];                // NORM only: A rows of a stage that hold real pixels (padding must stay zero)
+    unsigned wbyte[BP];
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+        const int co = n0 + r0 + RPP * j;
+        wbyte[j] = co < a.NOUT ? (unsigned)co * (unsigned)a.KTOT * 2u : OOB;
+    }
+    const bool early_b = !MULTI && (PLAIN || !a.s2) && !(FN_IG_DBG & 16);
+    {
+        const int kk0 = (KS == 1 ? 0 : grp) * BK + kg * 8;
+        const unsigned kb0 = (early_b && kk0 < a.KTOT) ? (unsigned)kk0 * 2u : OOB;
+#pragma unroll
+        for (int j = 0; j < BP; ++j) rb[0][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wbyte[j] + kb0), 0, 0);
+    }
     if constexpr (!PLAIN) {
         for (int i = tid; i < ntiles_k * 8; i += NT) {
             const int e = a.s2 ? ktab_entry_s2(i, a.CS, a.KH, a.KW, qy, qx) : ktab_entry(i, a.KTOT, a.CS, a.KW);
@@ -590,9 +610,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             sT[i] = t;
         }
     }
-    const int kg = gtid & 7, r0 = gtid >> 3;
     int ry[AP], rx[AP];
-    unsigned rbyte[AP], wbyte[BP];
+    unsigned rbyte[AP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int m = m0 + r0 + RPP * i;
@@ -624,19 +643,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             rbyte[i] = (unsigned)(((n * a.SH + ry[i]) * a.SW + rx[i]) * a.ld_src) * 2u;
         }
     }
-#pragma unroll
-    for (int j = 0; j < BP; ++j) {
-        const int co = n0 + r0 + RPP * j;
-        wbyte[j] = co < a.NOUT ? (unsigned)co * (unsigned)a.KTOT * 2u : OOB;
-    }
     __syncthreads();
 
     // DEPTH register stages: while tile kt is multiplied out of LDS, tiles kt+1 .. kt+DEPTH are loaded or in flight.
     // Most layers of this network run at <= 1-2 workgroups per CU with cold per-XCD L2s at every kernel start, so
     // nothing else hides the (MALL/HBM) load latency; small tiles have the registers to spare, large grids use DEPTH 1.
-    u32x4 ra[DEPTH][AP], rb[DEPTH][BP];   // tile t lives in register stage t % DEPTH
-    unsigned rmask[DEPTH];                // NORM only: A rows of a stage that hold real pixels (padding must stay zero)
-    auto load_tile = [&](int kt, u32x4 (&ra)[AP], u32x4 (&rb)[BP], unsigned& msk) {
+    auto load_tile = [&](int kt, u32x4 (&ra)[AP], u32x4 (&rb)[BP], unsigned& msk, const bool have_b = false) {
         unsigned mk = 0u;
         if constexpr (PLAIN) {
             if constexpr (MULTI) {   // pick the source of this k tile (uniform), same two loads per row as below
@@ -673,8 +685,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
                 ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, (int)(rbyte[i] + kb), 0, 0);
                 if constexpr (NORM) mk |= ((rbyte[i] + kb) < 0x40000000u ? 1u : 0u) << i;
             }
+            if (!have_b) {
 #pragma unroll
-            for (int j = 0; j < BP; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wbyte[j] + kb), 0, 0);
+                for (int j = 0; j < BP; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wbyte[j] + kb), 0, 0);
+            }
             }
         } else {
             const int4 t = sT[kt * 8 + kg];
@@ -695,8 +709,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
                 if constexpr (NORM) mk |= (off < 0x40000000u ? 1u : 0u) << i;
             }
             }
+            if (!have_b) {
 #pragma unroll
-            for (int j = 0; j < BP; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wbyte[j] + (unsigned)t.z), 0, 0);
+                for (int j = 0; j < BP; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wbyte[j] + (unsigned)t.z), 0, 0);
+            }
         }
         msk = mk;
     };
@@ -788,7 +804,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         const int n_iter = (ntiles_k + KS - 1) / KS;           // same trip count for every group (barriers are block-wide)
         auto tile_of = [&](int it) { return grp + KS * it; };   // it-th k tile of this group
 #pragma unroll
-        for (int d = 0; d < (FN_IG_DBG & 16 ? 0 : DEPTH); ++d) load_tile(min(tile_of(d), last), ra[d], rb[d], rmask[d]);
+        for (int d = 0; d < (FN_IG_DBG & 16 ? 0 : DEPTH); ++d) load_tile(min(tile_of(d), last), ra[d], rb[d], rmask[d], d == 0 && early_b);
         if constexpr (NORM) {
             // scale / shift of the source channels from the producer's statistic replicas -- AFTER the first operand loads have
             // been issued, so the two memory round trips overlap; (channel, replica quarter) pairs spread over all threads
