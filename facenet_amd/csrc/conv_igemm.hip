@@ -1730,6 +1730,9 @@ static int make_fwd_args(const fn_conv_desc* d, ConvArgs& a) {
     a.stats_rep_stride = d->stats_rep_stride;
     FN_REQUIRE((long)d->N * d->H * d->W * d->ld_x * 2 < (1L << 30) && (long)d->Cout * a.KTOT * 2 < (1L << 30),
                "conv_fwd: x or w exceeds the 1 GiB range of 32-bit buffer offsets");
+    // the epilogue addresses y and the residual with 32-bit byte offsets as well (buffer stores / loads, below 2 GiB)
+    FN_REQUIRE((long)a.M * d->ld_y * (d->out_f32 ? 4 : 2) < (1L << 31) && (!d->resid || (long)a.M * d->ld_res * 2 < (1L << 31)),
+               "conv_fwd: y or the residual exceeds the 2 GiB range of 32-bit byte offsets");
     a.src_bytes = d->N * d->H * d->W * d->ld_x * 2;
     a.w_bytes = d->Cout * a.KTOT * 2;
     FN_REQUIRE(valid_tile(d->tile_fwd), "conv_fwd: tile_fwd=%d is not one of {128,64,32}x{128,64,32} or 9000000 (halo)", d->tile_fwd);
@@ -1767,6 +1770,11 @@ static int make_dgrad_args(const fn_conv_desc* d, ConvArgs& a) {
     a.stats_replicas = 1;
     FN_REQUIRE((long)d->N * d->OH * d->OW * d->ld_y * 2 < (1L << 30) && (long)d->Cin * a.KTOT * 2 < (1L << 30),
                "conv_dgrad: dy or wt exceeds the 1 GiB range of 32-bit buffer offsets");
+    // the epilogue addresses dx (and everything of dx's geometry: the fused residual backward's tensors) and the forward output of
+    // the fused BatchNorm backward with 32-bit byte offsets (buffer stores / loads, below 2 GiB)
+    FN_REQUIRE((long)d->N * d->H * d->W * d->ld_x * (d->out_f32 ? 4 : 2) < (1L << 31) &&
+                   (!d->bn_y || (long)d->N * d->H * d->W * d->ld_bn_y * 2 < (1L << 31)),
+               "conv_dgrad: dx or bn_y exceeds the 2 GiB range of 32-bit byte offsets");
     a.src_bytes = d->N * d->OH * d->OW * d->ld_y * 2;
     a.w_bytes = d->Cin * a.KTOT * 2;
     FN_REQUIRE(valid_tile(d->tile_dgrad), "conv_dgrad: tile_dgrad=%d is not one of {128,64,32}x{128,64,32} or 9000000 (halo)", d->tile_dgrad);

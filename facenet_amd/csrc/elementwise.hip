@@ -820,6 +820,7 @@ extern "C" int fn_bn_relu_train_fwd(const void* y, int ld_y, void* z, int ld_z, 
     DT_CHECK(dtype);
     FN_REQUIRE(y && z && stats && beta && save_scale && save_shift && M > 0 && C > 0 && C % 8 == 0 && ld_y % 8 == 0 && ld_z % 8 == 0 &&
                    ld_y >= C && ld_z >= C && C <= 8192, "bn_fwd: bad arguments");
+    FN_REQUIRE((long)M * ld_z * 2 < (1L << 31), "bn_fwd: z exceeds the 2 GiB range of the 32-bit byte offsets its stores use");
     const int stripes = cdiv(C, 64);
     int rpb = cdiv((long)M * stripes, 2048);
     if (rpb < 32) rpb = 32;
@@ -834,6 +835,7 @@ extern "C" int fn_bn_relu_train_bwd(void* dz, int ld_d, const void* y, int ld_y,
     DT_CHECK(dtype);
     FN_REQUIRE(dz && y && beta && save_scale && save_shift && dbeta && acc && M > 0 && C > 0 && C % 8 == 0 && ld_d % 8 == 0 &&
                    ld_y % 8 == 0 && C <= 4096, "bn_bwd: bad arguments");
+    FN_REQUIRE((long)M * ld_d * 2 < (1L << 31), "bn_bwd: dz exceeds the 2 GiB range of the 32-bit byte offsets its stores use");
     hipStream_t st = (hipStream_t)stream;
     const int reps = acc_replicas > 0 ? acc_replicas : 1;
     if (!reduced) {
