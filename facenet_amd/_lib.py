@@ -54,6 +54,7 @@ _SIGNATURES = {
     "fn_conv2d_wgrad": [C.POINTER(ConvDesc), _p],
     "fn_conv2d_variant": [C.POINTER(ConvDesc), _i],
     "fn_block35_infer": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _i, _i, _p],
+    "fn_block35_infer_warm": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _i, _p, C.c_int64, _i, _p],
     "fn_block17_infer": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _i, _i, _p],
     "fn_block17_infer_warm": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _i, _p, C.c_int64, _i, _p],
     "fn_conv2d_arg_bytes": [],

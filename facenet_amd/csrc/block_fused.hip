@@ -488,6 +488,8 @@ struct Block35Args {
     float scale;
     int relu;
     int N;
+    const unsigned char* warm;     // optional warm-ahead range (see Block17Args / warm_range)
+    long warm_bytes;
 };
 
 template <typename T>
@@ -509,6 +511,10 @@ __global__ __launch_bounds__(512) void block35_infer_kernel(const Block35Args a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int img = blockIdx.x;
+    if (img >= a.N) {         // warm-ahead workgroup
+        warm_range(a.warm, a.warm_bytes, img - a.N, 512);
+        return;
+    }
     const unsigned short* xin = a.x + (long)img * NPIX * C;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xin), 0, NPIX * C * 2, 0x00020000);
     constexpr unsigned OOB = 0x60000000u;
@@ -754,7 +760,16 @@ extern "C" int fn_block17_infer_warm(const void* x, void* y, int N, const void* 
 extern "C" int fn_block35_infer(const void* x, void* y, int N, const void* const* w_1x1, const void* const* w_3x3, const void* w_up,
                                 const float* const* b_1x1, const float* const* b_3x3, const float* b_up, float scale, int relu, int dtype,
                                 void* stream) {
+    return fn_block35_infer_warm(x, y, N, w_1x1, w_3x3, w_up, b_1x1, b_3x3, b_up, scale, relu, nullptr, 0, dtype, stream);
+}
+
+// fn_block35_infer plus WARM_WGS workgroups that read [warm, warm + warm_bytes) into every XCD's L2 (see fn_block17_infer_warm).
+extern "C" int fn_block35_infer_warm(const void* x, void* y, int N, const void* const* w_1x1, const void* const* w_3x3, const void* w_up,
+                                     const float* const* b_1x1, const float* const* b_3x3, const float* b_up, float scale, int relu,
+                                     const void* warm, int64_t warm_bytes, int dtype, void* stream) {
     FN_REQUIRE(dtype == FN_BF16 || dtype == FN_F16, "dtype %d unsupported", dtype);
+    FN_REQUIRE((warm == nullptr) == (warm_bytes == 0) && warm_bytes >= 0 && warm_bytes < (1L << 31) && ((uintptr_t)warm & 15) == 0,
+               "block35_infer: warm range must be 16-byte aligned, below 2 GiB, and given with its size");
     FN_REQUIRE(x && y && x != y && N > 0 && w_1x1 && w_3x3 && w_up && b_1x1 && b_3x3 && b_up, "block35_infer: bad arguments");
     Block35Args a{};
     a.x = (const unsigned short*)x; a.y = (unsigned short*)y; a.w_up = (const unsigned short*)w_up; a.b_up = b_up;
@@ -764,6 +779,8 @@ extern "C" int fn_block35_infer(const void* x, void* y, int N, const void* const
         a.b_1x1[i] = b_1x1[i]; a.b_3x3[i] = b_3x3[i];
     }
     a.scale = scale; a.relu = relu; a.N = N;
+    a.warm = (const unsigned char*)warm; a.warm_bytes = (long)warm_bytes;
+    const int grid = N + (warm ? WARM_WGS : 0);
     constexpr int SLICE = 304 * 64, PATCH = (19 * 19 * 64 + 1023) / 1024 * 1024 + 1024;
     constexpr size_t smem = 3 * SLICE + 2 * PATCH + 2 * (SLICE + 96 * 64);
     static_assert(smem <= 160 * 1024 && 3 * 256 * 64 <= 2 * (SLICE + 96 * 64) && 304 * 36 * 4 <= 2 * PATCH, "block35 LDS plan");
@@ -771,7 +788,7 @@ extern "C" int fn_block35_infer(const void* x, void* y, int N, const void* const
     const int which = dtype == FN_BF16 ? 0 : 1;
     if (int rc = allow_big_lds(which == 0 ? reinterpret_cast<const void*>(block35_infer_kernel<__bf16>) : reinterpret_cast<const void*>(block35_infer_kernel<_Float16>),
                                ok[which], "block35_infer")) return rc;
-    if (dtype == FN_BF16) hipLaunchKernelGGL(block35_infer_kernel<__bf16>, dim3(N), dim3(512), smem, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(block35_infer_kernel<_Float16>, dim3(N), dim3(512), smem, (hipStream_t)stream, a);
+    if (dtype == FN_BF16) hipLaunchKernelGGL(block35_infer_kernel<__bf16>, dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(block35_infer_kernel<_Float16>, dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
     return check_launch("block35_infer");
 }

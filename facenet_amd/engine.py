@@ -884,9 +884,28 @@ class Lowering:
         b1, b3 = arr([_ptr(net.fold_bias, L.bn_off) for L in L1]), arr([_ptr(net.fold_bias, L.bn_off) for L in L3])
         reads = [self._ra(r.x)] + [region(net.W_infer, L.w_off, L.w_off + L.numel) for L in L1 + L3 + [Lu]] + \
                 [region(net.fold_bias, L.bn_off, L.bn_off + L.cout) for L in L1 + L3] + [region(net.P, Lu.bias_off, Lu.bias_off + Lu.cout)]
-        self._emit(self.fwd, "block35_fused:" + pre, net.lib.fn_block35_infer, _ptr(r.x.buf.act), _ptr(r.y.buf.act), self.N, w1, w3,
-                   _ptr(net.W_infer, Lu.w_off), b1, b3, _ptr(net.P, Lu.bias_off), r.extra["scale"], 1 if r.extra["relu"] else 0, self.dt,
-                   keep=(w1, w3, b1, b3), r=reads, w=[self._ra(r.y)])
+        warm, warm_bytes = self._warm_next_block(pre, ("tower_conv0/Conv2d_1x1", "tower_conv1/Conv2d_0a_1x1", "tower_conv2/Conv2d_0a_1x1",
+                                                       "tower_conv1/Conv2d_0b_3x3", "tower_conv2/Conv2d_0b_3x3", "tower_conv2/Conv2d_0c_3x3", "up"), reads)
+        self._emit(self.fwd, "block35_fused:" + pre, net.lib.fn_block35_infer_warm, _ptr(r.x.buf.act), _ptr(r.y.buf.act), self.N, w1, w3,
+                   _ptr(net.W_infer, Lu.w_off), b1, b3, _ptr(net.P, Lu.bias_off), r.extra["scale"], 1 if r.extra["relu"] else 0,
+                   warm, warm_bytes, self.dt, keep=(w1, w3, b1, b3), r=reads, w=[self._ra(r.y)])
+
+    def _warm_next_block(self, pre: str, names, reads: list):
+        """Warm-ahead range of a fused block launch: the inference weight packs of the NEXT block of the same kind (the launch's spare
+        workgroups read them into every XCD's L2: fn_block17_infer_warm).  (None, 0) for the last block or FACENET_WARM_AHEAD=0."""
+        net = self.net
+        head, _, idx = pre.rpartition("/")
+        if not (idx.isdigit() and f"{head}/{int(idx) + 1}/up" in net.layers and int(os.environ.get("FACENET_WARM_AHEAD", "1"))):
+            return None, 0
+        nxt = [net.layers[f"{head}/{int(idx) + 1}/{n}"] for n in names]
+        lo, hi = min(L.w_off for L in nxt), max(L.w_off + L.numel for L in nxt)
+        if hi - lo > 2 * sum(L.numel for L in nxt):          # the packs do not sit (nearly) back to back in the inference buffer
+            return None, 0
+        esz = net.W_infer.element_size()
+        lo -= lo % (16 // esz)
+        nbytes = min(((hi - lo) * esz + 15) // 16 * 16, (net.W_infer.numel() - lo) * esz // 16 * 16)
+        reads.append(region(net.W_infer, lo, hi))
+        return _ptr(net.W_infer, lo), nbytes
 
     def _fwd_block17(self, r: Rec):
         net, pre = self.net, r.extra["prefix"]
@@ -898,18 +917,8 @@ class Lowering:
                 [region(net.fold_bias, L.bn_off, L.bn_off + L.cout) for L in Ls[:4]] + [region(net.P, Ls[4].bias_off, Ls[4].bias_off + Ls[4].cout)]
         # warm-ahead: the launch's spare workgroups (180 images on 256 CUs) read the NEXT block's weight packs into every XCD's L2
         # (fn_block17_infer_warm): from memory the next block's weight stream costs 50 us per launch, from a warm L2 ~40
-        warm, warm_bytes = None, 0
-        head, _, idx = pre.rpartition("/")
-        if idx.isdigit() and f"{head}/{int(idx) + 1}/up" in net.layers and int(os.environ.get("FACENET_WARM_AHEAD", "1")):
-            nxt = [net.layers[f"{head}/{int(idx) + 1}/{n}"] for n in ("tower_conv0/Conv2d_1x1", "tower_conv1/Conv2d_0a_1x1",
-                                                                      "tower_conv1/Conv2d_0b_1x7", "tower_conv1/Conv2d_0c_7x1", "up")]
-            lo, hi = min(L.w_off for L in nxt), max(L.w_off + L.numel for L in nxt)
-            if hi - lo <= 2 * sum(L.numel for L in nxt):          # the five packs sit (nearly) back to back in the inference buffer
-                esz = net.W_infer.element_size()
-                lo -= lo % (16 // esz)
-                warm, warm_bytes = _ptr(net.W_infer, lo), ((hi - lo) * esz + 15) // 16 * 16
-                warm_bytes = min(warm_bytes, (net.W_infer.numel() - lo) * esz // 16 * 16)
-                reads = reads + [region(net.W_infer, lo, hi)]
+        warm, warm_bytes = self._warm_next_block(pre, ("tower_conv0/Conv2d_1x1", "tower_conv1/Conv2d_0a_1x1", "tower_conv1/Conv2d_0b_1x7",
+                                                       "tower_conv1/Conv2d_0c_7x1", "up"), reads)
         self._emit(self.fwd, "block17_fused:" + pre, net.lib.fn_block17_infer_warm, _ptr(r.x.buf.act), _ptr(r.y.buf.act), self.N, *ws, *bs,
                    r.extra["scale"], 1 if r.extra["relu"] else 0, warm, warm_bytes, self.dt, r=reads, w=[self._ra(r.y)])
 

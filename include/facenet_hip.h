@@ -144,6 +144,10 @@ int fn_block17_infer_warm(const void* x, void* y, int N, const void* w_t0, const
  * tower_conv2/Conv2d_0c_3x3; w_up / b_up: the `up` layer [256][96] and its bias.  Arrays of 3 device pointers (host arrays). */
 int fn_block35_infer(const void* x, void* y, int N, const void* const* w_1x1, const void* const* w_3x3, const void* w_up,
                      const float* const* b_1x1, const float* const* b_3x3, const float* b_up, float scale, int relu, int dtype, void* stream);
+/* fn_block35_infer plus the warm-ahead workgroups of fn_block17_infer_warm (same contract for warm / warm_bytes). */
+int fn_block35_infer_warm(const void* x, void* y, int N, const void* const* w_1x1, const void* const* w_3x3, const void* w_up,
+                          const float* const* b_1x1, const float* const* b_3x3, const float* b_up, float scale, int relu,
+                          const void* warm, int64_t warm_bytes, int dtype, void* stream);
 int fn_conv2d_fwd(const fn_conv_desc* d, void* stream);
 int fn_conv2d_dgrad(const fn_conv_desc* d, void* stream);
 int fn_conv2d_wgrad(const fn_conv_desc* d, void* stream);
