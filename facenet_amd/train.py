@@ -342,6 +342,7 @@ class Trainer:
                  r=[region(self.G), region(self.hyper)], w=[region(net.P), region(self.M), region(self.V), region(net.W_train)])
         self._op(self.opt_ops, "pack_transpose", lib.fn_pack_transpose, _ptr(net.W_train), _ptr(net.Wt_train), _ptr(net.table),
                  len(net.layers), net.max_layer_elems, self.dt, r=[region(net.W_train)], w=[region(net.Wt_train)])
+        n_buckets = int(os.environ.get("FACENET_DP_BUCKETS", n_buckets))      # tuning aid: gradient buckets of the data-parallel step
         self.buckets = self._make_buckets(n_buckets) if self.segmented else []
         self.comm_stream = torch.cuda.Stream(device=dev) if self.exchange else None
         self.streams = _streams_for(net, n_streams)
